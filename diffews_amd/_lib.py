@@ -1,0 +1,104 @@
+"""ctypes binding of libdiffews_hip.so (C ABI declared in include/diffews_hip.h).
+
+There is NO fallback: if the library is missing this raises, and every op in `ops.py` goes
+through it.  The product path never touches a CPU or plain-PyTorch implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffews_hip.so")
+
+BF16, F16 = 0, 1
+OUT_T, OUT_F32, OUT_NCHW_F32 = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _vp), ("W", _vp), ("C", _vp), ("bias", _vp), ("rowbias", _vp), ("residual", _vp),
+                ("workspace", _vp), ("workspace_bytes", _sz), ("a_elems", _i64), ("w_elems", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("lda", _i32), ("ldc", _i32), ("ldr", _i32),
+                ("taps", _i32), ("Cin", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32),
+                ("stride", _i32), ("pad", _i32), ("ups", _i32), ("rows_per_img", _i32),
+                ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),
+                ("batch", _i32), ("strideA", _i64), ("strideW", _i64), ("strideC", _i64), ("dtype", _i32)]
+
+
+class FsaArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("k_bank", _vp), ("v_bank", _vp), ("out", _vp),
+                ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32), ("n_bank", _i32), ("nshot", _i32),
+                ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldkb", _i32), ("ldvb", _i32), ("ldo", _i32),
+                ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("kb_bs", _i64), ("vb_bs", _i64), ("o_bs", _i64),
+                ("scale", _f32), ("dtype", _i32)]
+
+
+class XattnArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("out", _vp),
+                ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("L", _i32),
+                ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32),
+                ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("o_bs", _i64),
+                ("scale", _f32), ("dtype", _i32)]
+
+
+class GroupNormArgs(C.Structure):
+    _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("stats_ws", _vp), ("stats_ws_bytes", _sz),
+                ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("ldx", _i32), ("ldy", _i32),
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp),
+                ("rows", _i32), ("C", _i32), ("ldx", _i32), ("ldy", _i32), ("eps", _f32), ("dtype", _i32)]
+
+
+class ConvSmallArgs(C.Structure):
+    _fields_ = [("x", _vp), ("W", _vp), ("bias", _vp), ("y", _vp),
+                ("B", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("Cout", _i32), ("taps", _i32), ("ldy", _i32),
+                ("in_scale", _f32), ("out_scale", _f32), ("out_mode", _i32), ("dtype", _i32)]
+
+
+# every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dfw_version": (_i32, []),
+    "dfw_error_string": (C.c_char_p, [_i32]),
+    "dfw_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
+    "dfw_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
+    "dfw_fsa_attention": (_i32, [C.POINTER(FsaArgs), _vp]),
+    "dfw_cross_attention": (_i32, [C.POINTER(XattnArgs), _vp]),
+    "dfw_groupnorm": (_i32, [C.POINTER(GroupNormArgs), _vp]),
+    "dfw_groupnorm_workspace_bytes": (_sz, [C.POINTER(GroupNormArgs)]),
+    "dfw_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),
+    "dfw_conv_small": (_i32, [C.POINTER(ConvSmallArgs), _vp]),
+    "dfw_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "dfw_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dfw_concat_channels": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dfw_timestep_embedding": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dfw_seg_postprocess": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X kernels are not built. Run `python -m diffews_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU / PyTorch fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dfw_error_string(rc)
+        raise RuntimeError(f"{what} failed: [{rc}] {msg.decode() if msg else '?'}")

@@ -1,0 +1,50 @@
+"""Build libdiffews_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is a
+plain C-ABI shared object (include/diffews_hip.h) loaded through ctypes."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdiffews_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "diffews_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

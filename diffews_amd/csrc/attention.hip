@@ -1,0 +1,398 @@
+// KV-fusion flash attention for gfx950 (head_dim 64): softmax(q [k_own ; k_bank]^T * scale) [v_own ; v_bank].
+//
+// Keys come from two base pointers (the query pass' own K/V and the per-layer bank written by the
+// support pass); the reference's torch.cat (attention_processor.py:258,267) is never materialised.
+// Key order is the reference's: [own ; shot 0 ; shot 1 ; ...] with bank image = episode*nshot+shot.
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.
+// Per 64-key tile (K and V tiles double-buffered in LDS, register-staged issue-early/write-late):
+//   S^T[key][q]  = K . Q^T      8 x v_mfma_f32_32x32x16  (K fragment from LDS, Q fragment in VGPRs)
+//   online softmax: computing S transposed puts a whole score row (one q) in ONE lane (32 values,
+//                   the other 32 keys of the row in lane^32), so the row max / row sum are
+//                   in-register reductions + one v_permlane32_swap; exp2 with a folded scale.
+//   O^T[d][q]   += V^T . P^T    8 x MFMA; the S^T accumulator tile is reused directly as the B
+//                   operand (rows of S^T are the reduction index, no lane movement), V^T
+//                   fragments come from the row-major V tile via ds_read_b64_tr_b16.
+// fp32 accumulation and fp32 softmax statistics throughout.
+#include "common.h"
+
+namespace dfw {
+
+struct FsaP {
+  const char* q; const char* k; const char* v; const char* kb; const char* vb; char* out;
+  uint32_t q_bytes, k_bytes, v_bytes, kb_bytes, vb_bytes;
+  int batch, heads, n_q, n_kv, n_bank, nshot;
+  int ldq, ldk, ldv, ldkb, ldvb, ldo;
+  long long q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs;
+  float c;  // scale * log2(e)
+};
+
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::v4 lds_tr_read(const char* p);
+template <>
+__device__ __forceinline__ bf16x4 lds_tr_read<__bf16>(const char* p) {
+  using s16x4 = short __attribute__((ext_vector_type(4)));
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(bf16x4, r);
+}
+template <>
+__device__ __forceinline__ f16x4 lds_tr_read<_Float16>(const char* p) {
+  using s16x4 = short __attribute__((ext_vector_type(4)));
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(f16x4, r);
+}
+
+// Exchange a value with lane^32.  v_permlane32_swap swaps vdst[32..63] with src[0..31]; fed the
+// same value twice it leaves {own | low-half copy} in one register and {high-half copy | own} in
+// the other, so max/sum of the two is the cross-half reduction in every lane.
+// Written as inline asm: with the builtin, hipcc (ROCm 7.2) copy-propagates the second result
+// away when both inputs are copies of one value (r[1] is replaced by r[0]).  The s_nop covers the
+// VALU-write -> v_permlane read hazard (2 wait states), which hipcc does not pad inside asm.
+__device__ __forceinline__ void half_swap(float v, float& r0, float& r1) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  r0 = a;
+  r1 = b;
+}
+__device__ __forceinline__ float half_swap_max(float v) {
+  float r0, r1;
+  half_swap(v, r0, r1);
+  return fmaxf(r0, r1);
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+  float r0, r1;
+  half_swap(v, r0, r1);
+  return r0 + r1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_kernel(const FsaP p) {
+  constexpr int KT = 64;                 // keys per tile
+  constexpr int TILE = KT * 128;         // bytes of one K (or V) tile
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // [buf][K|V]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k, p.k_bytes);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v, p.v_bytes);
+  const __amdgpu_buffer_rsrc_t rkb = make_rsrc(p.kb ? p.kb : p.k, p.kb ? p.kb_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rvb = make_rsrc(p.vb ? p.vb : p.v, p.vb ? p.vb_bytes : 0u);
+
+  // ---- Q fragments: B operand, lane holds Q[q0+lr][16s + 8*lh + 0..7]
+  typename Tr<T>::v8 qf[4];
+  {
+    const int qrow = q0 + lr;
+    const uint32_t base = qrow < p.n_q
+        ? (uint32_t)(((size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + lh * 8) * sizeof(T)) : kOOB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = as_v8<T>(buf_load16(rq, base + (uint32_t)(s * 32)));
+  }
+
+  // ---- staging: thread loads chunks e = tid + 256*i (row = e>>3, chunk = e&7) of K and of V
+  const int srow0 = tid >> 3, sc = tid & 7;
+  uint32_t lds_k[2], lds_v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = srow0 + 32 * i;
+    lds_k[i] = row * 128 + ((sc ^ ((row >> 1) & 7)) << 4);
+    lds_v[i] = row * 128 + ((sc ^ (((row >> 1) & 1) << 2)) << 4);
+  }
+  // fragment read addresses
+  uint32_t kr[2];  // K rows kb*32 + lr, chunk lh (^ s<<5 per k-substep)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int row = kb * 32 + lr;
+    kr[kb] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
+  // V^T via transposed reads: lane (q4 = (lane&15)>>2, p4 = lane&3) addresses row keybase+q4,
+  // d = dbase + 4*p4 with dbase = db*32 + 16*((lane>>4)&1); keybase = kb*32 + 16t + 4*lh (+8).
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+
+  const int tiles_own = (p.n_kv + KT - 1) / KT;
+  const int tiles_bank = p.nshot > 0 ? (p.n_bank + KT - 1) / KT : 0;
+  const int ntiles = tiles_own + p.nshot * tiles_bank;
+
+  i32x4 gk[2], gv[2];
+  auto issue = [&](int t) {
+    // segment of tile t (uniform)
+    int seg = 0, tt = t;
+    if (t >= tiles_own) { seg = 1 + (t - tiles_own) / tiles_bank; tt = (t - tiles_own) % tiles_bank; }
+    const int key0 = tt * KT;
+    if (seg == 0) {
+      const size_t base = (size_t)b * p.k_bs + head * 64 + sc * 8;
+      const size_t basev = (size_t)b * p.v_bs + head * 64 + sc * 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int key = key0 + srow0 + 32 * i;
+        const bool ok = key < p.n_kv;
+        gk[i] = buf_load16(rk, ok ? (uint32_t)((base + (size_t)key * p.ldk) * sizeof(T)) : kOOB);
+        gv[i] = buf_load16(rv, ok ? (uint32_t)((basev + (size_t)key * p.ldv) * sizeof(T)) : kOOB);
+      }
+    } else {
+      const size_t img = (size_t)b * p.nshot + (seg - 1);
+      const size_t base = img * p.kb_bs + head * 64 + sc * 8;
+      const size_t basev = img * p.vb_bs + head * 64 + sc * 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int key = key0 + srow0 + 32 * i;
+        const bool ok = key < p.n_bank;
+        gk[i] = buf_load16(rkb, ok ? (uint32_t)((base + (size_t)key * p.ldkb) * sizeof(T)) : kOOB);
+        gv[i] = buf_load16(rvb, ok ? (uint32_t)((basev + (size_t)key * p.ldvb) * sizeof(T)) : kOOB);
+      }
+    }
+  };
+  auto write_lds = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(i32x4*)(buf + lds_k[i]) = gk[i];
+      *(i32x4*)(buf + TILE + lds_v[i]) = gv[i];
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  issue(0);
+  write_lds(smem);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) issue(t + 1);
+    const char* kbuf = smem + cur * 2 * TILE;
+    const char* vbuf = kbuf + TILE;
+
+    // valid keys in this tile (uniform)
+    int nvalid;
+    {
+      int tt = t, nseg = p.n_kv;
+      if (t >= tiles_own) { tt = (t - tiles_own) % tiles_bank; nseg = p.n_bank; }
+      nvalid = nseg - tt * KT;
+    }
+
+    // ---- S^T = K . Q^T
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        typename Tr<T>::v8 kf = as_v8<T>(*(const i32x4*)(kbuf + (kr[kb] ^ (ss << 5))));
+        s[kb] = Tr<T>::mfma(kf, qf[ss], s[kb]);
+      }
+    }
+    if (nvalid < KT) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= nvalid) s[kb][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax (row = this lane's q; its other 32 keys live in lane^32)
+    float mt = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+    mt = half_swap_max(mt);
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+    const float mc = m_new * p.c;
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kb][r] * p.c - mc);
+        s[kb][r] = e;
+        psum += e;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        typename Tr<T>::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (T)s[kb][8 * t2 + j];
+        const int keybase = kb * 32 + 16 * t2 + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int dcol = d * 32 + 16 * tg + 4 * tp;  // element column; chunk = dcol>>3
+          const int row0 = keybase + tq, row1 = row0 + 8;
+          const uint32_t a0 = row0 * 128 + ((((dcol >> 3) ^ (((row0 >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1);
+          const uint32_t a1 = row1 * 128 + ((((dcol >> 3) ^ (((row1 >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1);
+          typename Tr<T>::v4 lo = lds_tr_read<T>(vbuf + a0);
+          typename Tr<T>::v4 hi = lds_tr_read<T>(vbuf + a1);
+          typename Tr<T>::v8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+          o[d] = Tr<T>::mfma(vf, pf, o[d]);
+        }
+      }
+
+    if (more) write_lds(smem + (cur ^ 1) * 2 * TILE);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- normalise and store: lane owns q0+lr, d = db*32 + 8g + 4*lh + (0..3)
+  const float l_tot = half_swap_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + lr;
+  if (qrow < p.n_q) {
+    char* ob = p.out + ((size_t)b * p.o_bs + (size_t)qrow * p.ldo + head * 64) * sizeof(T);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv;
+        *(i32x2*)(ob + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(v);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-attention over a short context (L keys): one thread per query row, K/V of the (batch, head)
+// staged in LDS as fp32, online softmax in registers.
+struct XaP {
+  const char* q; const char* k; const char* v; char* out;
+  int batch, heads, n_q, L, ldq, ldk, ldv, ldo;
+  long long q_bs, k_bs, v_bs, o_bs;
+  float c;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_kernel(const XaP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+  float* Ks = (float*)smem_x;          // [L][64]
+  float* Vs = Ks + (size_t)p.L * 64;   // [L][64]
+  const int head = blockIdx.y, b = blockIdx.z;
+  for (int e = threadIdx.x; e < p.L * 8; e += 256) {
+    const int j = e >> 3, c8 = e & 7;
+    float f[8];
+    unpack8<T>(*(const i32x4*)(p.k + ((size_t)b * p.k_bs + (size_t)j * p.ldk + head * 64 + c8 * 8) * sizeof(T)), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Ks[j * 64 + c8 * 8 + i] = f[i];
+    unpack8<T>(*(const i32x4*)(p.v + ((size_t)b * p.v_bs + (size_t)j * p.ldv + head * 64 + c8 * 8) * sizeof(T)), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Vs[j * 64 + c8 * 8 + i] = f[i];
+  }
+  __syncthreads();
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.n_q) return;
+  float qv[64];
+  const char* qp = p.q + ((size_t)b * p.q_bs + (size_t)row * p.ldq + head * 64) * sizeof(T);
+#pragma unroll
+  for (int c8 = 0; c8 < 8; ++c8) unpack8<T>(*(const i32x4*)(qp + c8 * 16), qv + c8 * 8);
+  float o[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) o[i] = 0.f;
+  float m = -1e30f, l = 0.f;
+  for (int j = 0; j < p.L; ++j) {
+    float sdot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) sdot += qv[i] * Ks[j * 64 + i];
+    const float mn = fmaxf(m, sdot);
+    const float al = __builtin_amdgcn_exp2f((m - mn) * p.c), e = __builtin_amdgcn_exp2f((sdot - mn) * p.c);
+    m = mn;
+    l = l * al + e;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) o[i] = o[i] * al + e * Vs[j * 64 + i];
+  }
+  const float inv = 1.0f / l;
+  char* op = p.out + ((size_t)b * p.o_bs + (size_t)row * p.ldo + head * 64) * sizeof(T);
+#pragma unroll
+  for (int c8 = 0; c8 < 8; ++c8) {
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = o[c8 * 8 + i] * inv;
+    *(i32x4*)(op + c8 * 16) = pack8<T>(f);
+  }
+}
+
+}  // namespace dfw
+
+using namespace dfw;
+
+static int64_t extent(int batch, int64_t bs, int n, int ld, int heads) {
+  return (int64_t)(batch - 1) * bs + (int64_t)(n - 1) * ld + (int64_t)heads * 64;
+}
+
+extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->out) return DFW_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kv <= 0 || a->nshot < 0) return DFW_EINVAL;
+  if (a->nshot > 0 && (!a->k_bank || !a->v_bank || a->n_bank <= 0)) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8 != 0) return DFW_ESHAPE;
+  if (a->nshot > 0 && (a->ldkb | a->ldvb) % 8 != 0) return DFW_ESHAPE;
+  if ((a->q_bs | a->k_bs | a->v_bs | a->o_bs) % 8 != 0) return DFW_ESHAPE;
+  FsaP p;
+  p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v;
+  p.kb = (const char*)a->k_bank; p.vb = (const char*)a->v_bank; p.out = (char*)a->out;
+  const int64_t qe = extent(a->batch, a->q_bs, a->n_q, a->ldq, a->heads);
+  const int64_t ke = extent(a->batch, a->k_bs, a->n_kv, a->ldk, a->heads);
+  const int64_t ve = extent(a->batch, a->v_bs, a->n_kv, a->ldv, a->heads);
+  int64_t kbe = 0, vbe = 0;
+  if (a->nshot > 0) {
+    kbe = extent(a->batch * a->nshot, a->kb_bs, a->n_bank, a->ldkb, a->heads);
+    vbe = extent(a->batch * a->nshot, a->vb_bs, a->n_bank, a->ldvb, a->heads);
+  }
+  const int64_t lim = (1ll << 30);  // elements (2 bytes each)
+  if (qe >= lim || ke >= lim || ve >= lim || kbe >= lim || vbe >= lim) return DFW_ERANGE;
+  p.q_bytes = (uint32_t)(qe * 2); p.k_bytes = (uint32_t)(ke * 2); p.v_bytes = (uint32_t)(ve * 2);
+  p.kb_bytes = (uint32_t)(kbe * 2); p.vb_bytes = (uint32_t)(vbe * 2);
+  p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_kv = a->n_kv;
+  p.n_bank = a->n_bank; p.nshot = a->nshot;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldkb = a->ldkb; p.ldvb = a->ldvb; p.ldo = a->ldo;
+  p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.kb_bs = a->kb_bs; p.vb_bs = a->vb_bs; p.o_bs = a->o_bs;
+  p.c = a->scale * 1.4426950408889634f;
+  dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_cross_attention(const dfw_xattn_args* a, dfw_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->out) return DFW_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->L <= 0) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8 != 0) return DFW_ESHAPE;
+  if ((a->q_bs | a->k_bs | a->v_bs | a->o_bs) % 8 != 0) return DFW_ESHAPE;
+  const size_t lds = (size_t)a->L * 64 * 2 * sizeof(float);
+  if (lds > 64 * 1024) return DFW_ESHAPE;  // L <= 128
+  XaP p;
+  p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.out = (char*)a->out;
+  p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.L = a->L;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.o_bs = a->o_bs;
+  p.c = a->scale * 1.4426950408889634f;
+  dim3 grid((a->n_q + 255) / 256, a->heads, a->batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((xattn_kernel<__bf16>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((xattn_kernel<_Float16>), grid, dim3(256), lds, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}

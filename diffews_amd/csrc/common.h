@@ -1,0 +1,99 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16, 16-byte vector access).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diffews_hip.h"
+
+namespace dfw {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x2 = int __attribute__((ext_vector_type(2)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+using f16x4 = _Float16 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Tr;
+template <> struct Tr<__bf16> {
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Tr<_Float16> {
+  using v8 = f16x8;
+  using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
+
+template <typename T> __device__ __forceinline__ typename Tr<T>::v8 as_v8(i32x4 r) {
+  return __builtin_bit_cast(typename Tr<T>::v8, r);
+}
+template <typename T> __device__ __forceinline__ i32x4 as_i4(typename Tr<T>::v8 r) {
+  return __builtin_bit_cast(i32x4, r);
+}
+
+// 8 storage elements (16 B) <-> 8 floats
+template <typename T> __device__ __forceinline__ void unpack8(i32x4 r, float* f) {
+  typename Tr<T>::v8 v = as_v8<T>(r);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ i32x4 pack8(const float* f) {
+  typename Tr<T>::v8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (T)f[i];
+  return as_i4<T>(v);
+}
+template <typename T> __device__ __forceinline__ i32x2 pack4(const float* f) {
+  typename Tr<T>::v4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (T)f[i];
+  return __builtin_bit_cast(i32x2, v);
+}
+template <typename T> __device__ __forceinline__ void unpack4(i32x2 r, float* f) {
+  typename Tr<T>::v4 v = __builtin_bit_cast(typename Tr<T>::v4, r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+}
+
+// Bounds-checked 16-byte load through a buffer descriptor: offsets >= num_records read as zero,
+// which is how conv halos, ragged M/N tiles and key padding are produced without branches.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ i32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
+constexpr uint32_t kOOB = 0x80000000u;  // always >= num_records (tensors are < 2 GiB, checked on host)
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace dfw
+
+#define DFW_CHECK_LAUNCH()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)

@@ -1,0 +1,413 @@
+// Implicit-GEMM on MFMA for gfx950: Linear / conv1x1 / conv3x3 (stride 1|2, fused nearest-2x
+// upsample) on NHWC activations, with bias / time-embedding / residual / SiLU / GEGLU epilogues.
+//
+// Tile: BM x BN x 64, 256 threads = 4 waves in a 2x2 grid, each wave (BM/2)x(BN/2) built from
+// v_mfma_f32_32x32x16 blocks.  The MFMA is issued as D[n][m] = W_frag x A_frag so that every lane
+// ends up owning 4 *contiguous output channels* of one output row -> 8-byte vector stores and
+// vector bias / residual loads in the epilogue.
+//
+// LDS: double-buffered [BM+BN rows][64 k] storage-dtype tiles (128-byte rows), 16-byte chunks
+// XOR-swizzled by ((row>>1)&7) which makes both the ds_write_b128 (8 lanes = one row) and the
+// ds_read_b128 fragment reads (32 rows, same chunk) bank-conflict free (bank = (addr/4)%64).
+// Global->LDS staging goes through registers (issue-early / write-late): the loads for K-step
+// k+1 are issued before the MFMAs of step k and written to the other buffer after them, one
+// barrier per K-step.  All global loads are bounds-checked buffer loads, so conv halos, ragged
+// M tiles and N padding read as zero with no divergent branches.
+#include "common.h"
+
+namespace dfw {
+
+struct GemmP {
+  const char* A; const char* W; char* C;
+  const float* bias; const float* rowbias; const char* residual; float* partial;
+  uint32_t a_bytes, w_bytes;
+  int M, N, K, lda, ldc, ldr;
+  int taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups, rows_per_img;
+  float out_scale;
+  int act, geglu, out_mode, splitk, batch;
+  long long strideA, strideW, strideC;
+  int nk, cpt, ntn, ntm;
+};
+
+// Epilogue for 4 consecutive output channels n..n+3 of output row m (raw fp32 accumulators in v).
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n, float* v) {
+  const bool vec = (p.N & 3) == 0;
+  if (vec) {
+    if (p.bias) {
+      f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += b[i];
+    }
+    if (p.rowbias) {
+      f32x4 b = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_img) * p.N + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += b[i];
+    }
+    if (p.residual) {
+      float r[4];
+      unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < p.N) {
+        if (p.bias) v[i] += p.bias[n + i];
+        if (p.rowbias) v[i] += p.rowbias[(size_t)(m / p.rows_per_img) * p.N + n + i];
+        if (p.residual) v[i] += to_f(((const T*)p.residual)[(size_t)m * p.ldr + n + i]);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] *= p.out_scale;
+    if (p.act == DFW_ACT_SILU) v[i] = silu_f(v[i]);
+  }
+  if (p.out_mode == DFW_OUT_T && vec) {
+    *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
+  } else if (p.out_mode == DFW_OUT_F32 && vec) {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = o;
+  } else if (p.out_mode == DFW_OUT_NCHW_F32) {
+    const int img = m / p.rows_per_img, pix = m - img * p.rows_per_img;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < p.N) ((float*)Cb)[((size_t)img * p.N + n + i) * p.rows_per_img + pix] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < p.N) {
+        if (p.out_mode == DFW_OUT_T) ((T*)Cb)[(size_t)m * p.ldc + n + i] = from_f<T>(v[i]);
+        else ((float*)Cb)[(size_t)m * p.ldc + n + i] = v[i];
+      }
+  }
+}
+
+template <typename T, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, MB = WTM / 32, NB = WTN / 32;
+  constexpr int SA = BM / 32, SW = BN / 32;
+  constexpr int BUF = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
+  // XCD a contiguous run of tiles (neighbouring tiles share the A rows / W columns in its L2).
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tn = bid % p.ntn, tm = bid / p.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  int ks0 = 0, ks1 = p.nk;
+  const char* Ab = p.A;
+  const char* Wb = p.W;
+  char* Cb = p.C;
+  if (p.batch > 1) {
+    Ab += (size_t)z * p.strideA * sizeof(T);
+    Wb += (size_t)z * p.strideW * sizeof(T);
+    Cb += (size_t)z * p.strideC * (p.out_mode == DFW_OUT_T ? sizeof(T) : sizeof(float));
+  } else if (p.splitk > 1) {
+    ks0 = (int)((long long)z * p.nk / p.splitk);
+    ks1 = (int)((long long)(z + 1) * p.nk / p.splitk);
+  }
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wb, p.w_bytes);
+
+  // ---- per-thread staging slots: 16-byte chunk kc of rows (tid>>3) + 32*i
+  const int kc = tid & 7, srow = tid >> 3;
+  uint32_t a_off[SA];       // linear case: byte offset of the row (+chunk), or OOB
+  int a_iy0[SA], a_ix0[SA]; // conv case
+  uint32_t a_pix[SA];
+#pragma unroll
+  for (int i = 0; i < SA; ++i) {
+    const int m = m0 + srow + 32 * i;
+    if constexpr (!CONV) {
+      a_off[i] = m < p.M ? (uint32_t)(((size_t)m * p.lda + kc * 8) * sizeof(T)) : kOOB;
+    } else {
+      if (m < p.M) {
+        const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[i] = oy * p.stride - p.pad;
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_pix[i] = (uint32_t)img * (uint32_t)(p.Hi * p.Wi);
+      } else {
+        a_iy0[i] = -(1 << 20);
+        a_ix0[i] = 0;
+        a_pix[i] = 0;
+      }
+    }
+  }
+  uint32_t w_off[SW];
+#pragma unroll
+  for (int i = 0; i < SW; ++i) {
+    const int n = n0 + srow + 32 * i;
+    w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
+  }
+  // LDS write addresses (within a buffer)
+  uint32_t lds_wa[SA], lds_ww[SW];
+#pragma unroll
+  for (int i = 0; i < SA; ++i) {
+    const int row = srow + 32 * i;
+    lds_wa[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < SW; ++i) {
+    const int row = BM + srow + 32 * i;
+    lds_ww[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+  }
+  // LDS fragment read addresses (k-substep s adds ^ (s<<5))
+  uint32_t lds_ra[MB], lds_rw[NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int row = wm * WTM + i * 32 + lr;
+    lds_ra[i] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = BM + wn * WTN + i * 32 + lr;
+    lds_rw[i] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
+
+  i32x4 ga[SA], gw[SW];
+  int tap = 0, cc = 0;  // conv: current tap and channel chunk of the K-step being LOADED
+  if constexpr (CONV) {
+    tap = ks0 / p.cpt;
+    cc = ks0 - tap * p.cpt;
+  }
+  auto issue_loads = [&](int ks) {
+    if constexpr (!CONV) {
+#pragma unroll
+      for (int i = 0; i < SA; ++i) ga[i] = buf_load16(ra, a_off[i] + (uint32_t)ks * 128u);
+    } else {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const uint32_t coff = (uint32_t)(cc * 64 + kc * 8);
+#pragma unroll
+      for (int i = 0; i < SA; ++i) {
+        int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        bool ok;
+        if (p.ups) {
+          ok = (unsigned)iy < (unsigned)(2 * p.Hi) && (unsigned)ix < (unsigned)(2 * p.Wi);
+          iy >>= 1;
+          ix >>= 1;
+        } else {
+          ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        }
+        const uint32_t off = ((a_pix[i] + (uint32_t)(iy * p.Wi + ix)) * (uint32_t)p.lda + coff) * (uint32_t)sizeof(T);
+        ga[i] = buf_load16(ra, ok ? off : kOOB);
+      }
+      if (++cc == p.cpt) { cc = 0; ++tap; }
+    }
+#pragma unroll
+    for (int i = 0; i < SW; ++i) gw[i] = buf_load16(rw, w_off[i] + (uint32_t)ks * 128u);
+  };
+  auto write_lds = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < SA; ++i) *(i32x4*)(buf + lds_wa[i]) = ga[i];
+#pragma unroll
+    for (int i = 0; i < SW; ++i) *(i32x4*)(buf + lds_ww[i]) = gw[i];
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (ks0 < ks1) {
+    issue_loads(ks0);
+    write_lds(smem);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const bool more = ks + 1 < ks1;
+      if (more) issue_loads(ks + 1);
+      const char* buf = smem + cur * BUF;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        typename Tr<T>::v8 fa[MB], fw[NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[i] = as_v8<T>(*(const i32x4*)(buf + (lds_ra[i] ^ (s << 5))));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fw[j] = as_v8<T>(*(const i32x4*)(buf + (lds_rw[j] ^ (s << 5))));
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = Tr<T>::mfma(fw[j], fa[i], acc[i][j]);
+      }
+      if (more) write_lds(smem + (cur ^ 1) * BUF);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue: lane owns output row m = .. + lr, channels 8g + 4*lh + (0..3) of each 32-block
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + lr;
+    if (m >= p.M) continue;
+    if (p.geglu) {
+      if constexpr (NB >= 2) {
+#pragma unroll
+        for (int jp = 0; jp < NB / 2; ++jp)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int na = n0 + wn * WTN + (2 * jp) * 32 + 8 * g + 4 * lh;
+            if (na >= p.N) continue;
+            const int no = ((n0 + wn * WTN) >> 1) + jp * 32 + 8 * g + 4 * lh;
+            f32x4 ba = *(const f32x4*)(p.bias + na), bg = *(const f32x4*)(p.bias + na + 32);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = (acc[i][2 * jp][4 * g + e] + ba[e]) * gelu_erf(acc[i][2 * jp + 1][4 * g + e] + bg[e]);
+            *(i32x2*)(Cb + ((size_t)m * p.ldc + no) * sizeof(T)) = pack4<T>(v);
+          }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+        if (p.splitk > 1) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)(p.partial + ((size_t)z * p.M + m) * p.N + n) = o;
+        } else {
+          epilogue4<T>(p, Cb, m, n, v);
+        }
+      }
+  }
+}
+
+// split-K second pass: sum the fp32 slabs in split order (deterministic) and run the epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
+  const int nq = p.N >> 2;
+  const long long total = (long long)p.M * nq;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int m = (int)(e / nq), n = (int)(e - (long long)m * nq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int zz = 0; zz < p.splitk; ++zz) {
+      f32x4 t = *(const f32x4*)(p.partial + ((size_t)zz * p.M + m) * p.N + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    epilogue4<T>(p, p.C, m, n, v);
+  }
+}
+
+template <typename T, int BM, int BN>
+static int launch_tile(const GemmP& p, hipStream_t st) {
+  GemmP q = p;
+  q.ntm = (p.M + BM - 1) / BM;
+  q.ntn = (p.N + BN - 1) / BN;
+  dim3 grid(q.ntm * q.ntn, p.batch > 1 ? p.batch : (p.splitk > 1 ? p.splitk : 1));
+  const size_t lds = 2 * (BM + BN) * 128;
+  if (p.taps == 1) {
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false>), grid, dim3(256), lds, st, q);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true>), grid, dim3(256), lds, st, q);
+  }
+  DFW_CHECK_LAUNCH();
+  if (p.splitk > 1) {
+    const long long total = (long long)p.M * (p.N >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, q);
+    DFW_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+template <typename T>
+static int launch_gemm(const GemmP& p, hipStream_t st) {
+  // Tile choice: the 128x128 tile has the best MFMA:load ratio; fall back to narrower tiles when
+  // it would leave most of the 256 CUs idle or waste half a tile on N padding.
+  const bool n128 = (p.N % 128) == 0 || p.N >= 1024;
+  if (p.geglu) return launch_tile<T, 128, 128>(p, st);
+  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 1 ? p.batch : p.splitk);
+  if (p.M >= 128 && n128 && t128 >= 192) return launch_tile<T, 128, 128>(p, st);
+  if (p.M >= 128 && (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * (p.batch > 1 ? p.batch : p.splitk) >= 192)
+    return launch_tile<T, 128, 64>(p, st);
+  return launch_tile<T, 64, 64>(p, st);
+}
+
+}  // namespace dfw
+
+using namespace dfw;
+
+static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
+  if (!a || !a->A || !a->W || !a->C) return DFW_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  esz = 2;
+  if (a->taps != 1 && a->taps != 9) return DFW_ESHAPE;
+  if (a->Cin <= 0 || a->Cin % 64 != 0 || a->K != a->taps * a->Cin) return DFW_ESHAPE;
+  if (a->lda % 8 != 0) return DFW_ESHAPE;
+  if (a->out_mode == DFW_OUT_T && (a->N % 4 == 0) && (a->ldc % 4 != 0)) return DFW_ESHAPE;
+  if (a->residual && (a->N % 4 == 0) && (a->ldr % 4 != 0)) return DFW_ESHAPE;
+  if (a->a_elems <= 0 || a->w_elems <= 0) return DFW_EINVAL;
+  if (a->a_elems * esz >= (1ll << 31) || a->w_elems * esz >= (1ll << 31)) return DFW_ERANGE;
+  if (a->w_elems < (int64_t)a->N * a->K) return DFW_EINVAL;
+  const int batch = a->batch > 1 ? a->batch : 1;
+  const int splitk = a->splitk > 1 ? a->splitk : 1;
+  if (batch > 1 && splitk > 1) return DFW_ESHAPE;
+  if (a->geglu && (splitk > 1 || batch > 1 || a->N % 128 != 0 || !a->bias || a->out_mode != DFW_OUT_T ||
+                   a->residual || a->rowbias))
+    return DFW_ESHAPE;
+  if (splitk > 1 && (a->N % 4 != 0)) return DFW_ESHAPE;
+  if (a->taps == 9) {
+    if (a->Hi <= 0 || a->Wi <= 0 || a->Ho <= 0 || a->Wo <= 0 || a->stride <= 0) return DFW_EINVAL;
+    if (a->M % (a->Ho * a->Wo) != 0) return DFW_ESHAPE;
+    const int64_t need = (int64_t)(a->M / (a->Ho * a->Wo)) * a->Hi * a->Wi * a->lda;
+    if (a->a_elems < need - (a->lda - a->Cin)) return DFW_EINVAL;
+  } else {
+    if (a->a_elems < (int64_t)(a->M - 1) * a->lda + a->K) return DFW_EINVAL;
+  }
+  const int rpi = a->rows_per_img > 0 ? a->rows_per_img : (a->taps == 9 ? a->Ho * a->Wo : a->M);
+  if ((a->rowbias || a->out_mode == DFW_OUT_NCHW_F32) && rpi <= 0) return DFW_EINVAL;
+  p.A = (const char*)a->A; p.W = (const char*)a->W; p.C = (char*)a->C;
+  p.bias = a->bias; p.rowbias = a->rowbias; p.residual = (const char*)a->residual;
+  p.partial = (float*)a->workspace;
+  p.a_bytes = (uint32_t)(a->a_elems * esz);
+  p.w_bytes = (uint32_t)(a->w_elems * esz);
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldc = a->ldc; p.ldr = a->ldr;
+  p.taps = a->taps; p.Cin = a->Cin; p.Hi = a->Hi; p.Wi = a->Wi; p.Ho = a->Ho; p.Wo = a->Wo;
+  p.stride = a->stride; p.pad = a->pad; p.ups = a->ups; p.rows_per_img = rpi;
+  p.out_scale = a->out_scale; p.act = a->act; p.geglu = a->geglu; p.out_mode = a->out_mode;
+  p.splitk = splitk; p.batch = batch;
+  p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
+  p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
+  if (p.splitk > p.nk) p.splitk = p.nk;
+  return 0;
+}
+
+extern "C" size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a) {
+  if (!a || a->splitk <= 1) return 0;
+  return (size_t)a->splitk * (size_t)a->M * (size_t)a->N * sizeof(float);
+}
+
+extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
+  GemmP p;
+  int esz;
+  int rc = fill_params(a, p, esz);
+  if (rc) return rc;
+  if (p.splitk > 1) {
+    if (!a->workspace || a->workspace_bytes < (size_t)p.splitk * p.M * p.N * sizeof(float)) return DFW_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
+}

@@ -1,0 +1,293 @@
+// Small HBM-bound kernels around the MFMA path: boundary convs with tiny channel counts, row
+// softmax, transpose, channel concat, timestep embedding, segmentation post-processing + metric.
+#include "common.h"
+
+namespace dfw {
+
+// ---------------------------------------------------------------------------------------------
+// Direct conv, Cin <= 8, NCHW fp32 input.  thread = (pixel, block of 8 output channels).
+struct CsP {
+  const float* x; const float* W; const float* bias; char* y;
+  int B, Cin, H, Wd, Cout, taps, ldy, out_mode;
+  float in_scale, out_scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_small_kernel(const CsP p) {
+  __shared__ float ws[9 * 8 * 8];  // [tap][c][8 outputs]
+  __shared__ float bs[8];
+  const int co0 = blockIdx.y * 8;
+  const int tc = p.taps * p.Cin;
+  for (int e = threadIdx.x; e < tc * 8; e += 256) {
+    const int o = e & 7, k = e >> 3;
+    ws[e] = (co0 + o < p.Cout) ? p.W[(size_t)(co0 + o) * tc + k] : 0.f;
+  }
+  if (threadIdx.x < 8) bs[threadIdx.x] = (p.bias && co0 + threadIdx.x < p.Cout) ? p.bias[co0 + threadIdx.x] : 0.f;
+  __syncthreads();
+  const int HW = p.H * p.Wd;
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long long)p.B * HW) return;
+  const int b = (int)(pix / HW), rem = (int)(pix - (long long)b * HW);
+  const int y = rem / p.Wd, x = rem - y * p.Wd;
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  const int pad = p.taps == 9 ? 1 : 0;
+  for (int t = 0; t < p.taps; ++t) {
+    const int ky = p.taps == 9 ? t / 3 : 0, kx = p.taps == 9 ? t - ky * 3 : 0;
+    const int iy = y + ky - pad, ix = x + kx - pad;
+    if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.Wd) continue;
+    for (int c = 0; c < p.Cin; ++c) {
+      const float v = p.x[((size_t)(b * p.Cin + c) * p.H + iy) * p.Wd + ix] * p.in_scale;
+      const float* w = ws + (t * p.Cin + c) * 8;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) acc[o] += v * w[o];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = (acc[o] + bs[o]) * p.out_scale;
+  if (p.out_mode == DFW_OUT_T) {
+    *(i32x4*)(p.y + ((size_t)pix * p.ldy + co0) * sizeof(T)) = pack8<T>(acc);
+  } else {
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (co0 + o < p.Cout) ((float*)p.y)[((size_t)b * p.Cout + co0 + o) * HW + rem] = acc[o];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax: fp32 scores -> T probabilities.  One workgroup per row.
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, T* y, int L, float c) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * L;
+  T* yr = y + (size_t)blockIdx.x * L;
+  float m = -1e30f;
+  for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, xr[i]);
+  m = block_reduce(m, true, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) s += __builtin_amdgcn_exp2f((xr[i] - m) * c);
+  s = block_reduce(s, false, red);
+  const float inv = 1.0f / s;
+  for (int i = threadIdx.x; i < L; i += 256) yr[i] = from_f<T>(__builtin_amdgcn_exp2f((xr[i] - m) * c) * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched transpose of 2-byte elements through a padded LDS tile.
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* x, uint16_t* y, int R, int C) {
+  __shared__ uint16_t tile[64][66];
+  const size_t base = (size_t)blockIdx.z * R * C;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < R && c < C) tile[i][tx] = x[base + (size_t)r * C + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) y[base + (size_t)c * R + r] = tile[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void concat_kernel(const i32x4* a, const i32x4* b, i32x4* y, long long rows,
+                                                       int cha, int chb) {
+  const int nch = cha + chb;
+  const long long total = rows * nch;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / nch;
+    const int c = (int)(e - r * nch);
+    y[e] = c < cha ? a[r * cha + c] : b[r * chb + (c - cha)];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* t, T* out, int B, int dim, int flip, float shift) {
+  const int half = dim >> 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * half) return;
+  const int b = e / half, j = e - b * half;
+  const float freq = expf(-9.210340371976184f * (float)j / ((float)half - shift));
+  const float arg = t[b] * freq;
+  const float sn = sinf(arg), cs = cosf(arg);
+  T* o = out + (size_t)b * dim;
+  if (flip) { o[j] = from_f<T>(cs); o[half + j] = from_f<T>(sn); }
+  else { o[j] = from_f<T>(sn); o[half + j] = from_f<T>(cs); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Segmentation post-processing.  Pass 1: uint8 image + per-image max.  Pass 2: threshold + counts.
+__global__ __launch_bounds__(256) void seg_u8_kernel(const float* x, uint8_t* u8, uint32_t* mx, int per_img) {
+  const int b = blockIdx.y;
+  uint32_t m = 0;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < per_img; e += gridDim.x * 256) {
+    float v = x[(size_t)b * per_img + e];
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    v = (v * 0.5f + 0.5f) * 255.0f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    const uint32_t q = (uint32_t)v;  // truncation == numpy astype(uint8) on [0,255]
+    u8[(size_t)b * per_img + e] = (uint8_t)q;
+    m = max(m, q);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(mx + b, m);
+}
+
+__global__ __launch_bounds__(256) void seg_count_kernel(const uint8_t* u8, const uint8_t* gt, const uint32_t* mx,
+                                                        long long* counts, int HW, float r_thr) {
+  const int b = blockIdx.y;
+  const float thr = ((float)mx[b] / 255.0f) * r_thr;
+  // inter0, inter1, pred0, pred1, gt0, gt1
+  unsigned c[6] = {0, 0, 0, 0, 0, 0};
+  const uint8_t* ub = u8 + (size_t)b * 3 * HW;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += gridDim.x * 256) {
+    const float t0 = (float)ub[e] / 255.0f, t1 = (float)ub[HW + e] / 255.0f, t2 = (float)ub[2 * HW + e] / 255.0f;
+    const float mean = ((t0 + t1) + t2) / 3.0f;
+    const int g = gt[(size_t)b * HW + e];
+    if (g == 255) continue;  // ignore index: dropped from every histogram
+    const int pr = mean > thr ? 1 : 0;
+    c[2 + pr]++;
+    c[4 + (g ? 1 : 0)]++;
+    if (pr == (g ? 1 : 0)) c[pr]++;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+    c[k] = v;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    // counts[b] = {inter0, inter1, union0, union1}; union = pred + gt - inter
+    atomicAdd((unsigned long long*)(counts + b * 4 + 0), (unsigned long long)c[0]);
+    atomicAdd((unsigned long long*)(counts + b * 4 + 1), (unsigned long long)c[1]);
+    atomicAdd((unsigned long long*)(counts + b * 4 + 2), (unsigned long long)(c[2] + c[4] - c[0]));
+    atomicAdd((unsigned long long*)(counts + b * 4 + 3), (unsigned long long)(c[3] + c[5] - c[1]));
+  }
+}
+
+}  // namespace dfw
+
+using namespace dfw;
+
+extern "C" int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream) {
+  if (!a || !a->x || !a->W || !a->y) return DFW_EINVAL;
+  if (a->B <= 0 || a->H <= 0 || a->Wd <= 0 || a->Cout <= 0) return DFW_EINVAL;
+  if (a->Cin <= 0 || a->Cin > 8 || (a->taps != 1 && a->taps != 9)) return DFW_ESHAPE;
+  if (a->out_mode == DFW_OUT_T && (a->Cout % 8 != 0 || a->ldy % 8 != 0)) return DFW_ESHAPE;
+  if (a->out_mode != DFW_OUT_T && a->out_mode != DFW_OUT_NCHW_F32) return DFW_ESHAPE;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  CsP p;
+  p.x = a->x; p.W = a->W; p.bias = a->bias; p.y = (char*)a->y;
+  p.B = a->B; p.Cin = a->Cin; p.H = a->H; p.Wd = a->Wd; p.Cout = a->Cout; p.taps = a->taps;
+  p.ldy = a->ldy; p.out_mode = a->out_mode; p.in_scale = a->in_scale; p.out_scale = a->out_scale;
+  const long long pix = (long long)a->B * a->H * a->Wd;
+  dim3 grid((unsigned)((pix + 255) / 256), (a->Cout + 7) / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((conv_small_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_small_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_softmax_rows(const float* x, void* y, int64_t rows, int32_t L, float scale, int32_t dtype,
+                                dfw_stream_t stream) {
+  if (!x || !y || rows <= 0 || L <= 0 || rows > 0x7fffffff) return DFW_EINVAL;
+  const float c = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, st, x, (__bf16*)y, L, c);
+  else if (dtype == DFW_F16) hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, st, x, (_Float16*)y, L, c);
+  else return DFW_EINVAL;
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_transpose(const void* x, void* y, int32_t batch, int32_t R, int32_t C, int32_t dtype,
+                             dfw_stream_t stream) {
+  if (!x || !y || batch <= 0 || R <= 0 || C <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, R, C);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_concat_channels(const void* a, const void* b, void* y, int64_t rows, int32_t Ca, int32_t Cb,
+                                   int32_t dtype, dfw_stream_t stream) {
+  if (!a || !b || !y || rows <= 0 || Ca <= 0 || Cb <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  if (Ca % 8 != 0 || Cb % 8 != 0) return DFW_ESHAPE;
+  const long long total = rows * ((Ca + Cb) / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const i32x4*)a,
+                     (const i32x4*)b, (i32x4*)y, (long long)rows, Ca / 8, Cb / 8);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_timestep_embedding(const float* timesteps, void* out, int32_t B, int32_t dim,
+                                      int32_t flip_sin_to_cos, float freq_shift, int32_t dtype,
+                                      dfw_stream_t stream) {
+  if (!timesteps || !out || B <= 0 || dim <= 0 || (dim & 1)) return DFW_EINVAL;
+  const int n = B * (dim / 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((timestep_embedding_kernel<__bf16>), dim3((n + 255) / 256), dim3(256), 0, st, timesteps, (__bf16*)out, B, dim, flip_sin_to_cos, freq_shift);
+  else if (dtype == DFW_F16) hipLaunchKernelGGL((timestep_embedding_kernel<_Float16>), dim3((n + 255) / 256), dim3(256), 0, st, timesteps, (_Float16*)out, B, dim, flip_sin_to_cos, freq_shift);
+  else return DFW_EINVAL;
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_t* gt, int64_t* counts,
+                                   uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
+                                   dfw_stream_t stream) {
+  if (!x || !seg_u8 || !scratch || B <= 0 || H <= 0 || Wd <= 0) return DFW_EINVAL;
+  if (gt && !counts) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = H * Wd, per_img = 3 * HW;
+  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * sizeof(uint32_t), st);
+  if (e != hipSuccess) return (int)e;
+  int bx = (per_img + 255) / 256;
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(seg_u8_kernel, dim3(bx, B), dim3(256), 0, st, x, seg_u8, scratch, per_img);
+  DFW_CHECK_LAUNCH();
+  if (gt) {
+    e = hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int64_t), st);
+    if (e != hipSuccess) return (int)e;
+    int cx = (HW + 255) / 256;
+    if (cx > 256) cx = 256;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(cx, B), dim3(256), 0, st, (const uint8_t*)seg_u8, gt,
+                       (const uint32_t*)scratch, (long long*)counts, HW, r_threshold);
+    DFW_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dfw_version(void) { return 100; }
+
+extern "C" const char* dfw_error_string(int code) {
+  switch (code) {
+    case 0: return "success";
+    case DFW_EINVAL: return "invalid argument (null pointer or non-positive size)";
+    case DFW_ESHAPE: return "shape not supported by the gfx950 kernel (alignment / multiple-of constraint)";
+    case DFW_ERANGE: return "tensor exceeds the 2 GiB buffer-descriptor range";
+    case DFW_EWORKSPACE: return "workspace missing or too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}

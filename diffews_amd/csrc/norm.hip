@@ -1,0 +1,248 @@
+// GroupNorm(+SiLU) and LayerNorm on NHWC / [rows][C] activations for gfx950.
+// HBM-bound: 16-byte vector access, fp32 statistics, deterministic reductions (no atomics).
+#include "common.h"
+
+namespace dfw {
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics.  grid = (chunks, B); block = tpp*slots threads where tpp = C/8 threads
+// cover one pixel (8 channels each) and `slots` pixels are processed per step.  Each thread keeps
+// per-channel fp32 sum / sum-of-squares for its fixed 8 channels; the block then folds slots and
+// the channels of each group in a fixed order and writes one (sum, sumsq) pair per group:
+// part[b][chunk][g][2].
+struct GnP {
+  const char* x; char* y; const float* gamma; const float* beta; float* part;
+  int B, HW, C, groups, ldx, ldy, chunks, ppc;  // ppc = pixels per chunk
+  float eps;
+  int silu;
+};
+
+template <typename T>
+__global__ void gn_stats_kernel(const GnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_n[];
+  float* ls = (float*)smem_n;  // [slots][C][2]
+  const int tpp = p.C >> 3, slots = blockDim.x / tpp;
+  const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * p.ppc, p1 = min(p.HW, p0 + p.ppc);
+  float s[8], ss[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+  const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
+  for (int px = p0 + slot; px < p1; px += slots) {
+    float f[8];
+    unpack8<T>(*(const i32x4*)(xb + (size_t)px * p.ldx * sizeof(T)), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] += f[i]; ss[i] += f[i] * f[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ls[((size_t)slot * p.C + cc * 8 + i) * 2 + 0] = s[i];
+    ls[((size_t)slot * p.C + cc * 8 + i) * 2 + 1] = ss[i];
+  }
+  __syncthreads();
+  const int cpg = p.C / p.groups;
+  for (int g = threadIdx.x; g < p.groups; g += blockDim.x) {
+    float a = 0.f, a2 = 0.f;
+    for (int sl = 0; sl < slots; ++sl)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a += ls[((size_t)sl * p.C + c) * 2 + 0];
+        a2 += ls[((size_t)sl * p.C + c) * 2 + 1];
+      }
+    float* o = p.part + (((size_t)b * p.chunks + chunk) * p.groups + g) * 2;
+    o[0] = a;
+    o[1] = a2;
+  }
+}
+
+// Apply: each block first combines the chunk partials of its image in fp64 (fixed order) into
+// per-channel scale/shift in LDS, then streams its pixel range.
+template <typename T>
+__global__ void gn_apply_kernel(const GnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_n[];
+  float* sc = (float*)smem_n;   // [C]
+  float* sh = sc + p.C;         // [C]
+  float* gm = sh + p.C;         // [groups][2] mean, rstd
+  const int b = blockIdx.y;
+  const int cpg = p.C / p.groups;
+  for (int g = threadIdx.x; g < p.groups; g += blockDim.x) {
+    double a = 0.0, a2 = 0.0;
+    for (int ch = 0; ch < p.chunks; ++ch) {
+      const float* o = p.part + (((size_t)b * p.chunks + ch) * p.groups + g) * 2;
+      a += (double)o[0];
+      a2 += (double)o[1];
+    }
+    const double n = (double)p.HW * cpg;
+    const double mean = a / n;
+    double var = a2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gm[g * 2 + 0] = (float)mean;
+    gm[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float w = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+    const float r = gm[g * 2 + 1] * w;
+    sc[c] = r;
+    sh[c] = bb - gm[g * 2 + 0] * r;
+  }
+  __syncthreads();
+  const int tpp = p.C >> 3, slots = blockDim.x / tpp;
+  const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  const int p0 = blockIdx.x * p.ppc, p1 = min(p.HW, p0 + p.ppc);
+  if (slot >= slots) return;
+  float rs[8], rh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { rs[i] = sc[cc * 8 + i]; rh[i] = sh[cc * 8 + i]; }
+  const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
+  char* yb = p.y + ((size_t)b * p.HW * p.ldy + cc * 8) * sizeof(T);
+  for (int px = p0 + slot; px < p1; px += slots) {
+    float f[8];
+    unpack8<T>(*(const i32x4*)(xb + (size_t)px * p.ldx * sizeof(T)), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = f[i] * rs[i] + rh[i];
+      f[i] = p.silu ? silu_f(v) : v;
+    }
+    *(i32x4*)(yb + (size_t)px * p.ldy * sizeof(T)) = pack8<T>(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 8*64*MAXC), two-pass statistics.
+struct LnP {
+  const char* x; char* y; const float* gamma; const float* beta;
+  int rows, C, ldx, ldy;
+  float eps;
+};
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ln_kernel(const LnP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= p.rows) return;
+  const int nch = p.C >> 3;
+  float f[MAXC][8];
+  const char* xr = p.x + (size_t)row * p.ldx * sizeof(T);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      unpack8<T>(*(const i32x4*)(xr + ch * 16), f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / p.C;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; v += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
+  char* yr = p.y + (size_t)row * p.ldy * sizeof(T);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[8];
+      const f32x4 g0 = *(const f32x4*)(p.gamma + ch * 8), g1 = *(const f32x4*)(p.gamma + ch * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(p.beta + ch * 8), b1 = *(const f32x4*)(p.beta + ch * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+        o[4 + j] = (f[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      *(i32x4*)(yr + ch * 16) = pack8<T>(o);
+    }
+  }
+}
+
+}  // namespace dfw
+
+using namespace dfw;
+
+static int gn_geometry(const dfw_groupnorm_args* a, int& chunks, int& ppc, int& threads, int& slots) {
+  if (!a) return DFW_EINVAL;
+  if (a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->groups <= 0) return DFW_EINVAL;
+  if (a->C % 8 != 0 || a->C % a->groups != 0 || a->ldx % 8 != 0 || a->ldy % 8 != 0) return DFW_ESHAPE;
+  const int tpp = a->C / 8;
+  if (tpp > 1024) return DFW_ESHAPE;
+  slots = 256 / tpp;
+  if (slots < 1) slots = 1;
+  threads = tpp * slots;
+  // aim for ~2048 workgroups over the batch, at least `slots*4` pixels per chunk
+  int want = 2048 / a->B;
+  if (want < 1) want = 1;
+  ppc = (a->HW + want - 1) / want;
+  const int minp = slots * 4;
+  if (ppc < minp) ppc = minp;
+  chunks = (a->HW + ppc - 1) / ppc;
+  return 0;
+}
+
+extern "C" size_t dfw_groupnorm_workspace_bytes(const dfw_groupnorm_args* a) {
+  int chunks, ppc, threads, slots;
+  if (gn_geometry(a, chunks, ppc, threads, slots)) return 0;
+  return (size_t)a->B * chunks * a->groups * 2 * sizeof(float);
+}
+
+extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
+  int chunks, ppc, threads, slots;
+  int rc = gn_geometry(a, chunks, ppc, threads, slots);
+  if (rc) return rc;
+  if (!a->x || !a->y || !a->stats_ws) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  if (a->stats_ws_bytes < (size_t)a->B * chunks * a->groups * 2 * sizeof(float)) return DFW_EWORKSPACE;
+  GnP p;
+  p.x = (const char*)a->x; p.y = (char*)a->y; p.gamma = a->gamma; p.beta = a->beta;
+  p.part = (float*)a->stats_ws;
+  p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.ldy = a->ldy;
+  p.chunks = chunks; p.ppc = ppc; p.eps = a->eps; p.silu = a->silu;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds1 = (size_t)slots * a->C * 2 * sizeof(float);
+  const size_t lds2 = ((size_t)2 * a->C + 2 * a->groups) * sizeof(float);
+  if (lds1 > 64 * 1024 || lds2 > 64 * 1024) return DFW_ESHAPE;
+  dim3 grid(chunks, a->B);
+  if (a->dtype == DFW_BF16) {
+    hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, dim3(threads), lds1, st, p);
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), lds2, st, p);
+  } else {
+    hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, dim3(threads), lds1, st, p);
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), lds2, st, p);
+  }
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_layernorm(const dfw_layernorm_args* a, dfw_stream_t stream) {
+  if (!a || !a->x || !a->y || !a->gamma || !a->beta) return DFW_EINVAL;
+  if (a->rows <= 0 || a->C <= 0) return DFW_EINVAL;
+  if (a->C % 8 != 0 || a->ldx % 8 != 0 || a->ldy % 8 != 0 || a->C > 8 * 64 * 4) return DFW_ESHAPE;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  LnP p;
+  p.x = (const char*)a->x; p.y = (char*)a->y; p.gamma = a->gamma; p.beta = a->beta;
+  p.rows = a->rows; p.C = a->C; p.ldx = a->ldx; p.ldy = a->ldy; p.eps = a->eps;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((a->rows + 3) / 4);
+  const int nch = a->C / 8;
+  if (a->dtype == DFW_BF16) {
+    if (nch <= 64) hipLaunchKernelGGL((ln_kernel<__bf16, 1>), grid, dim3(256), 0, st, p);
+    else if (nch <= 128) hipLaunchKernelGGL((ln_kernel<__bf16, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((ln_kernel<__bf16, 4>), grid, dim3(256), 0, st, p);
+  } else {
+    if (nch <= 64) hipLaunchKernelGGL((ln_kernel<_Float16, 1>), grid, dim3(256), 0, st, p);
+    else if (nch <= 128) hipLaunchKernelGGL((ln_kernel<_Float16, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((ln_kernel<_Float16, 4>), grid, dim3(256), 0, st, p);
+  }
+  DFW_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,282 @@
+"""Host-side op wrappers: torch tensors (device memory + current stream only) -> C-ABI calls.
+
+Every function launches hand-written gfx950 kernels from libdiffews_hip.so on
+`torch.cuda.current_stream()`; nothing here computes with PyTorch.  Activations are NHWC
+(`[B, H, W, C]` or `[rows, C]`) in the engine storage dtype (bf16 or fp16).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"engine storage dtype must be bfloat16 or float16, got {t.dtype}")
+
+
+def _f32(t, name):
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous float32 tensor")
+    return t
+
+
+def auto_splitk(M, N, K):
+    nk = K // 64
+    tiles = math.ceil(M / 64) * math.ceil(N / 64)
+    if tiles >= 256 or nk < 8:
+        return 1
+    return max(1, min(nk // 4, math.ceil(512 / tiles)))
+
+
+def _gemm_call(a):
+    lib = L.lib()
+    ws = None
+    if a.splitk > 1:
+        nbytes = lib.dfw_gemm_workspace_bytes(C.byref(a))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_gemm(C.byref(a), _stream()), "dfw_gemm")
+
+
+def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.ACT_NONE, geglu=False,
+           out=None, out_f32=False, out_scale=1.0, splitk=None):
+    """y[M, N] = epi(x[M, K] @ w[N, K]^T).  x may be a row-strided view ([M, K] with stride (ld, 1))."""
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.is_contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    assert out.stride(1) == 1 and out.shape == (M, n_out)
+    a = L.GemmArgs()
+    a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.bias, a.rowbias = _p(_f32(bias, "bias")), _p(_f32(rowbias, "rowbias"))
+    if residual is not None:
+        assert residual.dtype == x.dtype and residual.stride(1) == 1 and residual.shape == (M, N)
+        a.residual, a.ldr = residual.data_ptr(), residual.stride(0)
+    a.a_elems = (M - 1) * x.stride(0) + K
+    a.w_elems = w.numel()
+    a.M, a.N, a.K, a.lda, a.ldc = M, N, K, x.stride(0), out.stride(0)
+    a.taps, a.Cin = 1, K
+    a.rows_per_img = rows_per_img
+    a.out_scale, a.act, a.geglu = out_scale, act, int(geglu)
+    a.out_mode = L.OUT_F32 if out.dtype == torch.float32 else L.OUT_T
+    a.splitk = (auto_splitk(M, N, K) if not geglu else 1) if splitk is None else splitk
+    a.batch, a.dtype = 1, _dt(x)
+    _gemm_call(a)
+    return out
+
+
+def bmm_nt(x, w, out_f32=False, out_scale=1.0):
+    """Batched y[b] = x[b] @ w[b]^T for contiguous x [Bt, M, K], w [Bt, N, K]."""
+    assert x.dim() == 3 and w.dim() == 3 and x.is_contiguous() and w.is_contiguous()
+    Bt, M, K = x.shape
+    N = w.shape[1]
+    out = torch.empty(Bt, M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    a = L.GemmArgs()
+    a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.a_elems, a.w_elems = M * K, N * K
+    a.M, a.N, a.K, a.lda, a.ldc = M, N, K, K, N
+    a.taps, a.Cin = 1, K
+    a.out_scale = out_scale
+    a.out_mode = L.OUT_F32 if out_f32 else L.OUT_T
+    a.splitk, a.batch = 1, Bt
+    a.strideA, a.strideW, a.strideC = M * K, N * K, M * N
+    a.dtype = _dt(x)
+    _gemm_call(a)
+    return out
+
+
+def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
+            out_nchw_f32=False, out_scale=1.0, splitk=None):
+    """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
+    pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
+    encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling."""
+    assert x.dim() == 4 and x.stride(3) == 1 and x.is_contiguous()
+    B, Hi, Wi, Cin = x.shape
+    assert w.shape == (cout, 9 * Cin) and w.dtype == x.dtype and w.is_contiguous()
+    if ups:
+        assert stride == 1 and pad == 1
+        Ho, Wo = 2 * Hi, 2 * Wi
+    elif stride == 1:
+        Ho, Wo = Hi, Wi
+    else:
+        Ho, Wo = (Hi + 2 * pad - 3) // stride + 1 if pad else Hi // 2, (Wi + 2 * pad - 3) // stride + 1 if pad else Wi // 2
+    M = B * Ho * Wo
+    if out_nchw_f32:
+        out = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
+    a = L.GemmArgs()
+    a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.bias, a.rowbias = _p(_f32(bias, "bias")), _p(_f32(rowbias, "rowbias"))
+    if residual is not None:
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == M * cout
+        a.residual, a.ldr = residual.data_ptr(), cout
+    a.a_elems, a.w_elems = x.numel(), w.numel()
+    a.M, a.N, a.K, a.lda, a.ldc = M, cout, 9 * Cin, Cin, cout
+    a.taps, a.Cin, a.Hi, a.Wi, a.Ho, a.Wo = 9, Cin, Hi, Wi, Ho, Wo
+    a.stride, a.pad, a.ups = stride, pad, int(ups)
+    a.rows_per_img = Ho * Wo
+    a.out_scale = out_scale
+    a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else L.OUT_T
+    a.splitk = (auto_splitk(M, cout, 9 * Cin) if cout % 4 == 0 else 1) if splitk is None else splitk
+    a.batch, a.dtype = 1, _dt(x)
+    _gemm_call(a)
+    return out
+
+
+def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None):
+    """KV-fusion self-attention.  q/k/v: [B, N, heads*64] views (token stride = stride(1));
+    k_bank/v_bank: [B*nshot, Nb, heads*64] views written by the support pass."""
+    B, N, Cq = q.shape
+    assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    out = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
+    a = L.FsaArgs()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.batch, a.heads, a.n_q, a.n_kv = B, heads, N, k.shape[1]
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), Cq
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), N * Cq
+    if nshot:
+        assert k_bank.shape[0] == B * nshot and k_bank.stride(2) == 1 and v_bank.stride(2) == 1
+        assert k_bank.dtype == q.dtype and v_bank.shape == k_bank.shape
+        a.k_bank, a.v_bank = k_bank.data_ptr(), v_bank.data_ptr()
+        a.n_bank, a.nshot = k_bank.shape[1], nshot
+        a.ldkb, a.ldvb, a.kb_bs, a.vb_bs = k_bank.stride(1), v_bank.stride(1), k_bank.stride(0), v_bank.stride(0)
+    a.scale = scale if scale is not None else 64 ** -0.5
+    a.dtype = _dt(q)
+    L.check(L.lib().dfw_fsa_attention(C.byref(a), _stream()), "dfw_fsa_attention")
+    return out
+
+
+def cross_attention(q, k, v, heads, scale=None):
+    """q [B, N, heads*64]; k/v [B, L, heads*64] views (short context)."""
+    B, N, Cq = q.shape
+    assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    out = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
+    a = L.XattnArgs()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.batch, a.heads, a.n_q, a.L = B, heads, N, k.shape[1]
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), Cq
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), N * Cq
+    a.scale = scale if scale is not None else 64 ** -0.5
+    a.dtype = _dt(q)
+    L.check(L.lib().dfw_cross_attention(C.byref(a), _stream()), "dfw_cross_attention")
+    return out
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False):
+    """GroupNorm (+SiLU) over NHWC x [B, H, W, C] (or [B, HW, C])."""
+    assert x.is_contiguous()
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    y = torch.empty_like(x)
+    a = L.GroupNormArgs()
+    a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
+    a.B, a.HW, a.C, a.groups, a.ldx, a.ldy = B, HW, Cc, groups, Cc, Cc
+    a.eps, a.silu, a.dtype = eps, int(silu), _dt(x)
+    lib = L.lib()
+    nbytes = lib.dfw_groupnorm_workspace_bytes(C.byref(a))
+    if nbytes == 0:
+        L.check(L.lib().dfw_groupnorm(C.byref(a), _stream()), "dfw_groupnorm")  # reports the shape error
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    a.stats_ws, a.stats_ws_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_groupnorm(C.byref(a), _stream()), "dfw_groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    assert x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    a = L.LayerNormArgs()
+    a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
+    a.rows, a.C, a.ldx, a.ldy, a.eps, a.dtype = x.shape[0], x.shape[1], x.stride(0), y.stride(0), eps, _dt(x)
+    L.check(L.lib().dfw_layernorm(C.byref(a), _stream()), "dfw_layernorm")
+    return y
+
+
+def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, out_scale=1.0):
+    """Boundary conv with Cin <= 8: x NCHW fp32 [B, Cin, H, W], w fp32 [Cout, taps, Cin]."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, Cin, H, W = x.shape
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == cout * taps * Cin
+    if nchw_f32_out:
+        y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty(B, H, W, cout, dtype=dtype, device=x.device)
+    a = L.ConvSmallArgs()
+    a.x, a.W, a.bias, a.y = x.data_ptr(), w.data_ptr(), _p(_f32(bias, "bias")), y.data_ptr()
+    a.B, a.Cin, a.H, a.Wd, a.Cout, a.taps, a.ldy = B, Cin, H, W, cout, taps, cout
+    a.in_scale, a.out_scale = in_scale, out_scale
+    a.out_mode = L.OUT_NCHW_F32 if nchw_f32_out else L.OUT_T
+    a.dtype = _DT[dtype]
+    L.check(L.lib().dfw_conv_small(C.byref(a), _stream()), "dfw_conv_small")
+    return y
+
+
+def softmax_rows(x, dtype, scale=1.0):
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    Lr = x.shape[-1]
+    rows = x.numel() // Lr
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().dfw_softmax_rows(x.data_ptr(), y.data_ptr(), rows, Lr, scale, _DT[dtype], _stream()),
+            "dfw_softmax_rows")
+    return y
+
+
+def transpose(x):
+    assert x.dim() == 3 and x.is_contiguous()
+    Bt, R, Cc = x.shape
+    y = torch.empty(Bt, Cc, R, dtype=x.dtype, device=x.device)
+    L.check(L.lib().dfw_transpose(x.data_ptr(), y.data_ptr(), Bt, R, Cc, _dt(x), _stream()), "dfw_transpose")
+    return y
+
+
+def concat_channels(a, b):
+    assert a.is_contiguous() and b.is_contiguous() and a.shape[:-1] == b.shape[:-1] and a.dtype == b.dtype
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    y = torch.empty(*a.shape[:-1], Ca + Cb, dtype=a.dtype, device=a.device)
+    rows = a.numel() // Ca
+    L.check(L.lib().dfw_concat_channels(a.data_ptr(), b.data_ptr(), y.data_ptr(), rows, Ca, Cb, _dt(a), _stream()),
+            "dfw_concat_channels")
+    return y
+
+
+def timestep_embedding(timesteps, dim, dtype, flip_sin_to_cos=True, freq_shift=0.0):
+    assert timesteps.dtype == torch.float32 and timesteps.is_contiguous() and timesteps.dim() == 1
+    out = torch.empty(timesteps.shape[0], dim, dtype=dtype, device=timesteps.device)
+    L.check(L.lib().dfw_timestep_embedding(timesteps.data_ptr(), out.data_ptr(), timesteps.shape[0], dim,
+                                           int(flip_sin_to_cos), float(freq_shift), _DT[dtype], _stream()),
+            "dfw_timestep_embedding")
+    return out
+
+
+def seg_postprocess(x, gt=None, r_threshold=0.25):
+    """x: decoder output [B, 3, H, W] fp32 -> (uint8 [B,3,H,W], counts int64 [B,4] or None)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[1] == 3
+    B, _, H, W = x.shape
+    u8 = torch.empty(B, 3, H, W, dtype=torch.uint8, device=x.device)
+    scratch = torch.empty(B, dtype=torch.int32, device=x.device)
+    counts = None
+    if gt is not None:
+        assert gt.dtype == torch.uint8 and gt.is_contiguous() and gt.shape == (B, H, W)
+        counts = torch.empty(B, 4, dtype=torch.int64, device=x.device)
+    L.check(L.lib().dfw_seg_postprocess(x.data_ptr(), u8.data_ptr(), _p(gt), _p(counts), scratch.data_ptr(),
+                                        B, H, W, float(r_threshold), _stream()), "dfw_seg_postprocess")
+    return u8, counts

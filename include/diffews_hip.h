@@ -1,0 +1,196 @@
+/*
+ * diffews_hip.h -- C ABI of libdiffews_hip.so, the MI355X (gfx950) kernel library behind the
+ * DiffewS hot path.
+ *
+ * The reference (ga1i13o/DiffewS) has no native code: every op below replaces a PyTorch /
+ * diffusers-0.25 / xformers library call made from the reference's Python hot path.  Each entry
+ * point cites the reference call site(s) it stands in for (paths relative to the reference root;
+ * U = diffews/models/unet_2d_condition.py, A = diffews/models/attention_processor.py,
+ * P = diffews/marigold_pipeline_rgb_latent_noise.py).
+ *
+ * Conventions:
+ *   - the caller owns every buffer; kernels never allocate, free or synchronise;
+ *   - pointers are raw device pointers; activations are NHWC / [rows][channels] row-major with an
+ *     explicit element stride per row, images and latents at the pipeline boundary are NCHW fp32;
+ *   - launches are asynchronous on the hipStream_t passed in (graph-capturable);
+ *   - return value: 0 on success, a negative DFW_E* code for a rejected argument, or a positive
+ *     hipError_t from the launch; no C++ exception crosses the boundary; no global mutable state.
+ */
+#ifndef DIFFEWS_HIP_H
+#define DIFFEWS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dfw_stream_t; /* hipStream_t */
+
+enum { DFW_BF16 = 0, DFW_F16 = 1 };                       /* storage dtype of activations/weights */
+enum { DFW_OUT_T = 0, DFW_OUT_F32 = 1, DFW_OUT_NCHW_F32 = 2 };
+enum { DFW_ACT_NONE = 0, DFW_ACT_SILU = 1 };
+enum {
+  DFW_EINVAL = -1,   /* null pointer / non-positive size */
+  DFW_ESHAPE = -2,   /* shape not supported by the kernel (alignment / multiple-of constraints) */
+  DFW_ERANGE = -3,   /* tensor exceeds the 2 GiB buffer-descriptor range */
+  DFW_EWORKSPACE = -4
+};
+
+int dfw_version(void);
+const char* dfw_error_string(int code);
+
+/*
+ * Implicit-GEMM on MFMA:  C[m][n] = epi( sum_k A(m,k) * W[n][k] ).
+ *   taps == 1: A is [M][lda] (a Linear layer / 1x1 conv on NHWC tokens):
+ *              to_q/to_k/to_v/to_out (A:237-245, A:276), proj_in/proj_out, GEGLU proj, FF out,
+ *              time_embedding / time_emb_proj (U:1015), conv_shortcut, VAE attention projections.
+ *   taps == 9: A is the im2col view of an NHWC image [B][Hi][Wi][lda>=Cin], k = (ky*3+kx)*Cin + c:
+ *              every conv3x3 of ResnetBlock2D / Downsample2D / Upsample2D / conv_out
+ *              (U:1161-1171, U:1191, U:1226-1243, U:1249; VAE encoder/decoder P:852, P:902).
+ *              `ups` fuses the nearest-2x upsample of Upsample2D into the load indexing.
+ *   W is [N][K] row-major (K = taps*Cin), i.e. nn.Linear.weight, or conv weight permuted to
+ *   [Cout][ky][kx][Cin].
+ *   epi: + bias[n] + rowbias[m / rows_per_img][n] + residual[m][n], * out_scale, optional SiLU;
+ *        geglu != 0: W rows are interleaved in 64-row groups (32 value rows, 32 gate rows) and
+ *        C[m][j] = (a + bias_a) * gelu(g + bias_g)  (diffusers GEGLU), C has N/2 columns.
+ *   batch > 1: independent GEMMs at strideA/strideW/strideC elements (VAE attention QK^T, PV).
+ *   splitk > 1: K is split over `splitk` workgroups per tile; `workspace` must hold
+ *               splitk*M*N floats (dfw_gemm_workspace_bytes).
+ */
+typedef struct {
+  const void* A; const void* W; void* C;
+  const float* bias; const float* rowbias; const void* residual;
+  void* workspace; size_t workspace_bytes;
+  int64_t a_elems, w_elems;           /* extent of A / W in elements (for bounds-checked loads) */
+  int32_t M, N, K;
+  int32_t lda, ldc, ldr;
+  int32_t taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups;
+  int32_t rows_per_img;
+  float out_scale;
+  int32_t act, geglu, out_mode, splitk;
+  int32_t batch; int64_t strideA, strideW, strideC;
+  int32_t dtype;
+} dfw_gemm_args;
+
+int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);
+size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a);
+
+/*
+ * KV-fusion self-attention (the DiffewS-specific op): out = softmax(q [k_own ; k_bank]^T * scale) [v_own ; v_bank]
+ * Replaces xformers.ops.memory_efficient_attention + the bank concat of MyXFormersAttnProcessor
+ * (A:247-271).  q/k/v/out are [batch][tokens][heads*64] views with element row strides; the bank
+ * holds `nshot` reference images per episode, ref image index = episode*nshot + shot (A:256-257,
+ * evaluation_util/main_oss.py:103), each with n_bank tokens; keys are visited in the reference
+ * order [own ; shot0 ; shot1 ; ...] without materialising the concat.  nshot == 0: plain
+ * self-attention (bank-fill pass, A:251-252).  head_dim must be 64.
+ */
+typedef struct {
+  const void* q; const void* k; const void* v;
+  const void* k_bank; const void* v_bank; void* out;
+  int32_t batch, heads, n_q, n_kv, n_bank, nshot;
+  int32_t ldq, ldk, ldv, ldkb, ldvb, ldo;      /* element strides between tokens */
+  int64_t q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs; /* element strides between batch items */
+  float scale;
+  int32_t dtype;
+} dfw_fsa_args;
+
+int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream);
+
+/*
+ * Cross-attention over a short context (attn2 of BasicTransformerBlock; L = 2 prompt tokens at
+ * inference P:591-600, 77 in training).  q/out [batch][n_q][heads*64]; k/v [batch][L][heads*64].
+ */
+typedef struct {
+  const void* q; const void* k; const void* v; void* out;
+  int32_t batch, heads, n_q, L;
+  int32_t ldq, ldk, ldv, ldo;
+  int64_t q_bs, k_bs, v_bs, o_bs;
+  float scale;
+  int32_t dtype;
+} dfw_xattn_args;
+
+int dfw_cross_attention(const dfw_xattn_args* a, dfw_stream_t stream);
+
+/*
+ * GroupNorm (+ optional SiLU) on NHWC: torch.nn.GroupNorm of ResnetBlock2D.norm1/norm2,
+ * Transformer2DModel.norm, conv_norm_out (U:1247-1248), VAE attention group_norm.
+ * Two launches: statistics (deterministic two-level reduction, fp32 partials, fp64 combine)
+ * then apply.  `stats_ws` must hold dfw_groupnorm_workspace_bytes().
+ */
+typedef struct {
+  const void* x; void* y; const float* gamma; const float* beta;
+  void* stats_ws; size_t stats_ws_bytes;
+  int32_t B, HW, C, groups, ldx, ldy;
+  float eps;
+  int32_t silu;
+  int32_t dtype;
+} dfw_groupnorm_args;
+
+int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream);
+size_t dfw_groupnorm_workspace_bytes(const dfw_groupnorm_args* a);
+
+/* LayerNorm over the last dim of [rows][C] (BasicTransformerBlock.norm1/2/3). */
+typedef struct {
+  const void* x; void* y; const float* gamma; const float* beta;
+  int32_t rows, C, ldx, ldy;
+  float eps;
+  int32_t dtype;
+} dfw_layernorm_args;
+
+int dfw_layernorm(const dfw_layernorm_args* a, dfw_stream_t stream);
+
+/*
+ * Direct convolution for tiny channel counts on the pipeline boundary (NCHW fp32 in):
+ * conv_in / conv_in_ref (U:1119-1121), VAE encoder.conv_in, decoder.conv_in, quant_conv,
+ * post_quant_conv (P:853, P:901).  Cin <= 8.  W is [Cout][taps][Cin] fp32.
+ * out_mode DFW_OUT_T: NHWC storage dtype (Cout % 8 == 0); DFW_OUT_NCHW_F32: NCHW fp32.
+ * y = (conv(x * in_scale) + bias) * out_scale.
+ */
+typedef struct {
+  const float* x; const float* W; const float* bias; void* y;
+  int32_t B, Cin, H, Wd, Cout, taps, ldy;
+  float in_scale, out_scale;
+  int32_t out_mode;
+  int32_t dtype;
+} dfw_conv_small_args;
+
+int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream);
+
+/* Row softmax of fp32 scores -> storage dtype probabilities (VAE mid-block attention, 1 head of
+ * dim 512: diffusers Attention.get_attention_scores with upcast_softmax).  y = softmax(x*scale). */
+int dfw_softmax_rows(const float* x, void* y, int64_t rows, int32_t L, float scale, int32_t dtype,
+                     dfw_stream_t stream);
+
+/* Batched 2-D transpose of storage-dtype matrices: y[b][c][r] = x[b][r][c]. */
+int dfw_transpose(const void* x, void* y, int32_t batch, int32_t R, int32_t C, int32_t dtype,
+                  dfw_stream_t stream);
+
+/* Channel concat of two NHWC tensors (torch.cat([h, skip], dim=1) in the up blocks, U:1226). */
+int dfw_concat_channels(const void* a, const void* b, void* y, int64_t rows, int32_t Ca, int32_t Cb,
+                        int32_t dtype, dfw_stream_t stream);
+
+/* Sinusoidal timestep embedding, flip_sin_to_cos, fp32 math (diffusers Timesteps, U:1008);
+ * out [B][dim] in storage dtype. */
+int dfw_timestep_embedding(const float* timesteps, void* out, int32_t B, int32_t dim,
+                           int32_t flip_sin_to_cos, float freq_shift, int32_t dtype,
+                           dfw_stream_t stream);
+
+/*
+ * Segmentation post-processing on device (P:790-795, P:534; evaluation_util/main_oss.py:128-137;
+ * evaluation_util/common/evaluation.py:24-38): from decoder output x [B][3][H][W] fp32 (already
+ * clipped to [-1,1]) produce seg_u8 = uint8(clip((x*0.5+0.5)*255, 0, 255)) [B][3][H][W],
+ * and when `gt` is non-null the per-episode 2x2 intersection/union pixel counts of
+ * pred = (mean_c(u8/255) > r_threshold * max(u8/255)) against gt [B][H][W] (uint8 0/1, 255 = ignore)
+ * into counts [B][4] int64 = {inter0, inter1, union0, union1}.
+ * scratch: B uint32 words (per-image max), zeroed by this call.
+ */
+int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_t* gt, int64_t* counts,
+                        uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
+                        dfw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFEWS_HIP_H */

@@ -1,0 +1,261 @@
+"""GPU parity of every HIP op against a plain PyTorch fp32 reference of the same op.
+
+Inputs are rounded to the storage dtype first, so the reference sees exactly the operands the
+kernel sees; the kernels accumulate in fp32, so the only differences are accumulation order and
+the final rounding of the output to the storage dtype (tolerances below state this).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+# relative L2 tolerance: output rounding (2^-9 bf16 / 2^-12 fp16, rms ~ 0.6x) + fp32 accumulation order
+TOL = {torch.bfloat16: 4e-3, torch.float16: 6e-4}
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    from diffews_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 320, 320), (4096, 960, 320), (130, 64, 1280),
+                                   (64, 1280, 2560), (8, 256, 1024), (1000, 192, 128)])
+def test_linear(ops, dtype, M, N, K):
+    x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias = torch.randn(N)
+    res = rnd((M, N), dtype, 3)
+    ref = x.float() @ w.float().t() + bias + res.float()
+    y = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda())
+    assert rel(y, ref) < TOL[dtype]
+    y32 = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out_f32=True)
+    assert rel(y32, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("splitk", [1, 2, 5])
+def test_linear_splitk_rowbias_silu(ops, dtype, splitk):
+    M, N, K, rpi = 96, 128, 640, 32
+    x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias, rb = torch.randn(N), torch.randn(M // rpi, N)
+    ref = F.silu((x.float() @ w.float().t() + bias + rb.repeat_interleave(rpi, 0)) * 0.5)
+    y = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), rowbias=rb.cuda(), rows_per_img=rpi, act=1,
+                   out_scale=0.5, splitk=splitk)
+    assert rel(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_strided_view(ops, dtype):
+    """A operand as a column slice of a wider buffer (q/k/v views of the fused QKV output)."""
+    M, K, N = 300, 128, 192
+    big = rnd((M, 3 * K), dtype, 5)
+    w = rnd((N, K), dtype, 6, K ** -0.5)
+    y = ops.linear(big.cuda()[:, K:2 * K], w.cuda())
+    assert rel(y, big[:, K:2 * K].float() @ w.float().t()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu(ops, dtype):
+    from diffews_amd.packing import pack_geglu
+    M, C = 260, 128
+    x = rnd((M, C), dtype, 1)
+    w, b = rnd((8 * C, C), dtype, 2, C ** -0.5), torch.randn(8 * C) * 0.1
+    h = x.float() @ w.float().t() + b
+    a, g = h.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    wp, bp = pack_geglu(w, b)
+    y = ops.linear(x.cuda(), wp.cuda(), bias=bp.cuda(), geglu=True)
+    assert y.shape == (M, 4 * C)
+    assert rel(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pad,ups", [
+    (2, 16, 16, 64, 64, 1, 1, False), (1, 12, 20, 128, 320, 1, 1, False), (2, 16, 16, 64, 128, 2, 1, False),
+    (2, 16, 16, 64, 64, 2, 0, False), (1, 8, 8, 128, 64, 1, 1, True), (3, 8, 8, 1280, 1280, 1, 1, False),
+    (1, 64, 64, 128, 128, 1, 1, False)])
+def test_conv3x3(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
+    from diffews_amd.packing import pack_conv3x3
+    x = rnd((B, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)
+    bias = torch.randn(Cout)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if stride == 2 and pad == 0:
+        xin = F.pad(xin, (0, 1, 0, 1))
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=pad)
+    rb = torch.randn(B, Cout)
+    ref = ref + rb[:, :, None, None]
+    y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv3x3(w).cuda(), Cout, bias=bias.cuda(),
+                    stride=stride, pad=pad, ups=ups, rowbias=rb.cuda())
+    assert rel(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cout", [3, 4, 8])
+def test_conv3x3_small_cout_nchw(ops, dtype, Cout):
+    from diffews_amd.packing import pack_conv3x3
+    B, H, W, Cin = 2, 16, 24, 128
+    x = rnd((B, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)
+    bias = torch.randn(Cout)
+    ref = -F.conv2d(x.float(), w.float(), bias, padding=1)
+    y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv3x3(w).cuda(), Cout, bias=bias.cuda(),
+                    out_nchw_f32=True, out_scale=-1.0)
+    assert y.shape == ref.shape and rel(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,N,nshot", [(1, 1, 64, 0), (2, 2, 256, 0), (2, 2, 256, 1), (1, 5, 200, 2),
+                                             (2, 1, 16, 3), (1, 2, 1024, 1), (2, 3, 100, 0)])
+def test_fsa_attention(ops, dtype, B, heads, N, nshot):
+    """Empty bank == plain SDPA; with a bank == SDPA over [own ; shot0 ; shot1 ...] per episode
+    (attention_processor.py:256-258: ref image = episode*nshot + shot)."""
+    C = heads * 64
+    qkv = rnd((B, N, 3 * C), dtype, 1)
+    bank = rnd((max(B * nshot, 1), N, 3 * C), dtype, 2)
+    q, k, v = qkv.float().split(C, dim=-1)
+    if nshot:
+        kb, vb = bank.float()[..., C:2 * C], bank.float()[..., 2 * C:]
+        k = torch.cat([k, kb.reshape(B, nshot * N, C)], dim=1)
+        v = torch.cat([v, vb.reshape(B, nshot * N, C)], dim=1)
+    sh = lambda t: t.reshape(B, -1, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v)).transpose(1, 2).reshape(B, N, C)
+    qg, bg = qkv.cuda(), bank.cuda()
+    y = ops.fsa_attention(qg[..., :C], qg[..., C:2 * C], qg[..., 2 * C:], heads,
+                          k_bank=bg[..., C:2 * C] if nshot else None, v_bank=bg[..., 2 * C:] if nshot else None,
+                          nshot=nshot)
+    assert rel(y, ref) < 1.5 * TOL[dtype]  # + P rounded to the storage dtype before PV
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fsa_attention_online_softmax_rescale(ops, dtype):
+    """Force the running-max rescale branch: one late key dominates each query row."""
+    B, heads, N = 1, 1, 256
+    C = 64
+    q, k, v = rnd((B, N, C), dtype, 1), rnd((B, N, C), dtype, 2), rnd((B, N, C), dtype, 3)
+    k[0, 200] = q[0, 17] * 4  # spike in the 4th key tile
+    k[0, 70] = q[0, 100] * 3
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    y = ops.fsa_attention(q.cuda(), k.cuda(), v.cuda(), heads)
+    assert rel(y, ref) < 1.5 * TOL[dtype]
+    assert rel(y[0, 17], ref[0, 17]) < 3 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("L", [2, 77])
+def test_cross_attention(ops, dtype, L):
+    B, heads, N = 2, 3, 300
+    C = heads * 64
+    q, kv = rnd((B, N, C), dtype, 1), rnd((B, L, 2 * C), dtype, 2)
+    sh = lambda t: t.reshape(B, -1, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(q.float()), sh(kv.float()[..., :C]), sh(kv.float()[..., C:]))
+    ref = ref.transpose(1, 2).reshape(B, N, C)
+    kvg = kv.cuda()
+    y = ops.cross_attention(q.cuda(), kvg[..., :C], kvg[..., C:], heads)
+    assert rel(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 64, True), (1, 1000, 320, False), (3, 64, 2560, True),
+                                         (2, 4096, 128, True), (1, 16, 1920, True)])
+def test_groupnorm(ops, dtype, B, HW, C, silu):
+    x = rnd((B, HW, C), dtype, 1) * 2 + 0.5
+    g, b = torch.randn(C) * 0.2 + 1, torch.randn(C) * 0.2
+    ref = F.group_norm(x.float().transpose(1, 2), 32, g, b, eps=1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), 32, 1e-5, silu)
+    assert rel(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(100, 64), (1000, 320), (257, 640), (64, 1280)])
+def test_layernorm(ops, dtype, rows, C):
+    x = rnd((rows, C), dtype, 1) * 3 + 1
+    g, b = torch.randn(C) * 0.2 + 1, torch.randn(C) * 0.2
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5)
+    assert rel(ops.layernorm(x.cuda(), g.cuda(), b.cuda()), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cin,Cout,taps,nchw", [(3, 64, 9, False), (8, 320, 9, False), (4, 512, 9, False),
+                                                (8, 4, 1, True), (4, 4, 1, True)])
+def test_conv_small(ops, dtype, Cin, Cout, taps, nchw):
+    B, H, W = 2, 20, 12
+    x = torch.randn(B, Cin, H, W)
+    k = 3 if taps == 9 else 1
+    w = torch.randn(Cout, Cin, k, k) * (taps * Cin) ** -0.5
+    bias = torch.randn(Cout)
+    ref = (F.conv2d(x * 0.5, w, bias, padding=k // 2)) * 2.0
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, taps, Cin).contiguous()
+    y = ops.conv_small(x.cuda(), wp.cuda(), bias.cuda(), Cout, taps, dtype, nchw_f32_out=nchw, in_scale=0.5,
+                       out_scale=2.0)
+    if nchw:
+        assert rel(y, ref) < 1e-5
+    else:
+        assert rel(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_transpose_concat_bmm(ops, dtype):
+    s = torch.randn(3, 50, 264) * 4
+    y = ops.softmax_rows(s.cuda(), dtype, scale=0.3)
+    assert rel(y, torch.softmax(s * 0.3, -1)) < TOL[dtype]
+    x = rnd((3, 70, 136), dtype, 1)
+    assert torch.equal(ops.transpose(x.cuda()).cpu(), x.transpose(1, 2).contiguous())
+    a, b = rnd((2, 5, 7, 64), dtype, 2), rnd((2, 5, 7, 128), dtype, 3)
+    assert torch.equal(ops.concat_channels(a.cuda(), b.cuda()).cpu(), torch.cat([a, b], -1))
+    p, q = rnd((3, 100, 128), dtype, 4), rnd((3, 72, 128), dtype, 5)
+    assert rel(ops.bmm_nt(p.cuda(), q.cuda(), out_f32=True), p.float() @ q.float().transpose(1, 2)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding(ops, dtype):
+    t = torch.tensor([1.0, 500.0, 999.0])
+    half = 160
+    freq = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    e = t[:, None] * freq[None]
+    ref = torch.cat([torch.cos(e), torch.sin(e)], -1)
+    y = ops.timestep_embedding(t.cuda(), 320, dtype)
+    assert (y.float().cpu() - ref).abs().max() < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
+def test_seg_postprocess_bit_exact(ops):
+    """uint8 image and inter/union counts are integer work: bit-exact against the reference formulas
+    (pipeline P:790-795,534; main_oss.py:128-137; evaluation.py:24-38)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 3, 40, 56
+    x = (torch.rand(B, 3, H, W, generator=g) * 2.4 - 1.2)
+    gt = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+    gt[1][torch.rand(H, W, generator=g) > 0.9] = 255
+    u8, counts = ops.seg_postprocess(x.cuda(), gt.cuda(), 0.25)
+    seg = (x.clip(-1, 1).clip(-1.0, 1.0) * 0.5 + 0.5) * 255
+    ref_u8 = seg.clip(0, 255).numpy().astype(np.uint8)
+    assert np.array_equal(u8.cpu().numpy(), ref_u8)
+    for b in range(B):
+        pred = torch.from_numpy(ref_u8[b]).float().div(255)[None]
+        pm = (pred.mean(dim=1) > pred.max() * 0.25).float()[0]
+        g_ = gt[b].float()
+        pm[g_ == 255] = 255
+        same = pm[pm == g_]
+        inter = torch.histc(same, bins=2, min=0, max=1)
+        union = torch.histc(pm, bins=2, min=0, max=1) + torch.histc(g_, bins=2, min=0, max=1) - inter
+        assert counts[b].cpu().tolist() == [int(inter[0]), int(inter[1]), int(union[0]), int(union[1])]
