@@ -19,7 +19,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 class GemmArgs(C.Structure):
     _fields_ = [("A", _vp), ("W", _vp), ("C", _vp), ("bias", _vp), ("rowbias", _vp), ("residual", _vp),
                 ("workspace", _vp), ("workspace_bytes", _sz), ("a_elems", _i64), ("w_elems", _i64),
-                ("M", _i32), ("N", _i32), ("K", _i32), ("lda", _i32), ("ldc", _i32), ("ldr", _i32),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("lda", _i32), ("ldc", _i32), ("ldr", _i32), ("ld_rowbias", _i32),
                 ("taps", _i32), ("Cin", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32),
                 ("stride", _i32), ("pad", _i32), ("ups", _i32), ("rows_per_img", _i32),
                 ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),

@@ -21,7 +21,7 @@ struct GemmP {
   const char* A; const char* W; char* C;
   const float* bias; const float* rowbias; const char* residual; float* partial;
   uint32_t a_bytes, w_bytes;
-  int M, N, K, lda, ldc, ldr;
+  int M, N, K, lda, ldc, ldr, ldrb;
   int taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups, rows_per_img;
   float out_scale;
   int act, geglu, out_mode, splitk, batch;
@@ -40,7 +40,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
       for (int i = 0; i < 4; ++i) v[i] += b[i];
     }
     if (p.rowbias) {
-      f32x4 b = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_img) * p.N + n);
+      f32x4 b = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_img) * p.ldrb + n);
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += b[i];
     }
@@ -55,7 +55,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
     for (int i = 0; i < 4; ++i)
       if (n + i < p.N) {
         if (p.bias) v[i] += p.bias[n + i];
-        if (p.rowbias) v[i] += p.rowbias[(size_t)(m / p.rows_per_img) * p.N + n + i];
+        if (p.rowbias) v[i] += p.rowbias[(size_t)(m / p.rows_per_img) * p.ldrb + n + i];
         if (p.residual) v[i] += to_f(((const T*)p.residual)[(size_t)m * p.ldr + n + i]);
       }
   }
@@ -359,6 +359,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   if (a->lda % 8 != 0) return DFW_ESHAPE;
   if (a->out_mode == DFW_OUT_T && (a->N % 4 == 0) && (a->ldc % 4 != 0)) return DFW_ESHAPE;
   if (a->residual && (a->N % 4 == 0) && (a->ldr % 4 != 0)) return DFW_ESHAPE;
+  if (a->rowbias && a->ld_rowbias > 0 && (a->ld_rowbias % 4 != 0 || a->ld_rowbias < a->N)) return DFW_ESHAPE;
   if (a->a_elems <= 0 || a->w_elems <= 0) return DFW_EINVAL;
   if (a->a_elems * esz >= (1ll << 31) || a->w_elems * esz >= (1ll << 31)) return DFW_ERANGE;
   if (a->w_elems < (int64_t)a->N * a->K) return DFW_EINVAL;
@@ -385,6 +386,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.a_bytes = (uint32_t)(a->a_elems * esz);
   p.w_bytes = (uint32_t)(a->w_elems * esz);
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldc = a->ldc; p.ldr = a->ldr;
+  p.ldrb = a->ld_rowbias > 0 ? a->ld_rowbias : a->N;
   p.taps = a->taps; p.Cin = a->Cin; p.Hi = a->Hi; p.Wi = a->Wi; p.Ho = a->Ho; p.Wo = a->Wo;
   p.stride = a->stride; p.pad = a->pad; p.ups = a->ups; p.rows_per_img = rpi;
   p.out_scale = a->out_scale; p.act = a->act; p.geglu = a->geglu; p.out_mode = a->out_mode;

@@ -35,6 +35,15 @@ def _f32(t, name):
     return t
 
 
+def _rowbias(a, rb):
+    """rowbias [imgs, N] fp32, rows may be strided (a column slice of a wider buffer)."""
+    if rb is None:
+        return
+    if rb.dtype != torch.float32 or rb.dim() != 2 or rb.stride(1) != 1:
+        raise TypeError("rowbias must be float32 [imgs, N] with unit column stride")
+    a.rowbias, a.ld_rowbias = rb.data_ptr(), rb.stride(0)
+
+
 def auto_splitk(M, N, K):
     nk = K // 64
     tiles = math.ceil(M / 64) * math.ceil(N / 64)
@@ -66,7 +75,8 @@ def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.A
     assert out.stride(1) == 1 and out.shape == (M, n_out)
     a = L.GemmArgs()
     a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
-    a.bias, a.rowbias = _p(_f32(bias, "bias")), _p(_f32(rowbias, "rowbias"))
+    a.bias = _p(_f32(bias, "bias"))
+    _rowbias(a, rowbias)
     if residual is not None:
         assert residual.dtype == x.dtype and residual.stride(1) == 1 and residual.shape == (M, N)
         a.residual, a.ldr = residual.data_ptr(), residual.stride(0)
@@ -125,7 +135,8 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
         out = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
     a = L.GemmArgs()
     a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
-    a.bias, a.rowbias = _p(_f32(bias, "bias")), _p(_f32(rowbias, "rowbias"))
+    a.bias = _p(_f32(bias, "bias"))
+    _rowbias(a, rowbias)
     if residual is not None:
         assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == M * cout
         a.residual, a.ldr = residual.data_ptr(), cout

@@ -1,0 +1,218 @@
+"""Few-shot segmentation pipeline with the reference's interface, running on the MI355X engine.
+
+Drop-in for `MarigoldPipelineRGBLatentNoise`
+(/root/reference/diffews/marigold_pipeline_rgb_latent_noise.py:99): same constructor / `__call__`
+signature (P:126-138, P:223-238), `test_timestep` attribute (evaluation_util/main_oss.py:373),
+`enable_xformers_memory_efficient_attention()` (E:376, no-op), `single_infer` (P:617),
+`encode_rgb` (P:839), `decode_seg` (P:887).
+
+Differences that are deliberate:
+  * the CLIP text tower on "" (P:585-601) is constant per checkpoint: pass `text_embeds`
+    ([1, L, cross_attention_dim]); a `text_encoder`+`tokenizer` pair is used once if given;
+  * `rgb_paths` is ignored (the reference opens each path and throws the result away, P:312-316);
+  * inner batching uses the explicit `batch_size`, not the VRAM lookup table (P:397-407);
+  * `run_episodes()` is the fused fast path the launcher/bench use: z0 = -v is folded into the
+    UNet's conv_out epilogue and the threshold + intersection/union counts stay on device.
+Only the segmentation task is implemented; the reference treats every mode except 'depth' as
+'seg' (`mode == 'seg' or 'semseg'` is always truthy, P:280).
+"""
+from dataclasses import dataclass
+from typing import List, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .scheduler import DDIMSchedulerCustomized
+
+
+@dataclass
+class MarigoldSegOutput:
+    seg_colored: Union["PIL.Image.Image", List["PIL.Image.Image"]]
+    uncertainty: Union[None, np.ndarray]
+
+
+def chw2hwc(chw):
+    """marigold/util/image_util.py:55."""
+    assert chw.ndim == 3
+    return np.moveaxis(chw, 0, -1) if isinstance(chw, np.ndarray) else chw.permute(1, 2, 0)
+
+
+class MarigoldPipelineRGBLatentNoise:
+    rgb_latent_scale_factor = 0.18215   # P:120-124
+    seg_latent_scale_factor = 0.18215
+
+    def __init__(self, unet, vae, scheduler, tokenizer=None, text_embeds=None, text_encoder=None,
+                 image_encoder=None, image_projector=None, controlnet=None, customized_head=None):
+        if image_encoder is not None or image_projector is not None or controlnet is not None or customized_head is not None:
+            raise NotImplementedError("image_encoder / image_projector / controlnet / customized_head are always "
+                                      "None on the DiffewS path (evaluation_util/main_oss.py:355-364)")
+        if text_embeds is None and text_encoder is None:
+            raise ValueError("need text_embeds ([1, L, cross_attention_dim]) or a text_encoder + tokenizer")  # P:160-161
+        self.unet, self.vae, self.scheduler = unet, vae, scheduler
+        self.tokenizer, self.text_encoder = tokenizer, text_encoder
+        self.empty_text_embed = text_embeds
+        self.test_timestep = 1
+        self.device = unet.device
+        self.dtype = unet.dtype
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ reference surface
+    @classmethod
+    def from_pretrained(cls, checkpoint=None, unet=None, vae=None, scheduler=None, tokenizer=None, text_embeds=None,
+                        text_encoder=None, controlnet=None, image_projector=None, customized_head=None,
+                        image_encoder=None, torch_dtype=None, **kw):
+        from .unet import MyUNet2DConditionModel
+        from .vae import AutoencoderKL
+        dt = torch_dtype or torch.bfloat16
+        if unet is None:
+            unet = MyUNet2DConditionModel.from_pretrained(checkpoint, subfolder="unet", torch_dtype=dt)
+        if vae is None:
+            vae = AutoencoderKL.from_pretrained(checkpoint, subfolder="vae", torch_dtype=dt)
+        if scheduler is None:
+            scheduler = DDIMSchedulerCustomized.from_pretrained(checkpoint, subfolder="scheduler")
+        return cls(unet, vae, scheduler, tokenizer=tokenizer, text_embeds=text_embeds, text_encoder=text_encoder,
+                   image_encoder=image_encoder, image_projector=image_projector, controlnet=controlnet,
+                   customized_head=customized_head)
+
+    def to(self, device=None, dtype=None):
+        self.unet.to(device, dtype)
+        self.vae.to(device, dtype)
+        self.device, self.dtype = self.unet.device, self.unet.dtype
+        self._graphs = {}
+        return self
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None
+
+    def encode_clip_feature(self, clip_rgb_in=None):
+        """P:585-601; evaluated once, the prompt is the constant ""."""
+        if self.empty_text_embed is None:
+            ids = self.tokenizer("", padding="do_not_pad", max_length=self.tokenizer.model_max_length,
+                                 truncation=True, return_tensors="pt").input_ids
+            with torch.no_grad():
+                self.empty_text_embed = self.text_encoder(ids.to(self.text_encoder.device))[0]
+        return self.empty_text_embed
+
+    def encode_rgb(self, rgb_in):
+        """P:839-862: mean of quant_conv(encoder(x)) times the latent scale (no sampling)."""
+        h = self.vae.encoder(rgb_in.to(self.device))
+        lc = self.vae.config["latent_channels"]
+        moments = self.vae.quant_conv(h, out_scale=self.rgb_latent_scale_factor)
+        return moments[:, :lc].contiguous()
+
+    def decode_seg(self, seg_latent):
+        """P:887-905."""
+        z = self.vae.post_quant_conv(seg_latent.to(self.device), in_scale=1.0 / self.seg_latent_scale_factor)
+        return self.vae.decoder(z).clip(-1, 1)
+
+    @torch.no_grad()
+    def single_infer(self, rgb_in_ref, rgb_in_tag, gt_in_ref, clip_rgb_in=None, num_inference_steps=1,
+                     show_pbar=False, mode="seg", seed=None, return_latents=False):
+        """P:617-802, generic scheduler path (any number of denoising steps)."""
+        self.scheduler.set_timesteps(num_inference_steps, device=self.device)
+        z_ref, z_tag, z_gt = self.encode_rgb(rgb_in_ref), self.encode_rgb(rgb_in_tag), self.encode_rgb(gt_in_ref)
+        cond_ref = torch.cat([z_ref, z_gt], dim=1)   # P:674
+        z = z_tag.clone()                            # P:675
+        b = z_tag.shape[0]
+        embed = self.encode_clip_feature(clip_rgb_in).to(self.device)
+        ehs = embed.repeat((b, 1, 1))                # P:690
+        ehs_ref = ehs.repeat((z_ref.shape[0] // b, 1, 1))  # P:692
+        step_out = None
+        for t in self.scheduler.timesteps:
+            self.unet.clear_attn_bank()              # P:715
+            self.unet(cond_ref, t * self.test_timestep, encoder_hidden_states=ehs_ref, is_target=False)  # P:719-720
+            noise_pred = self.unet(z, t * self.test_timestep, encoder_hidden_states=ehs).sample          # P:721-724
+            self.unet.clear_attn_bank()              # P:725
+            step_out = self.scheduler.step(noise_pred, t, z)   # P:764
+            z = step_out.prev_sample
+        z0 = step_out.pred_original_sample           # P:769
+        seg = self.decode_seg(z0)
+        seg = (torch.clip(seg, -1.0, 1.0) * 0.5 + 0.5) * 255  # P:790-795
+        if return_latents:
+            return seg, dict(z_ref=z_ref, z_tag=z_tag, z_gt=z_gt, z0=z0)
+        return seg
+
+    # ------------------------------------------------------------------ fused fast path
+    @torch.no_grad()
+    def run_episodes(self, support_imgs, query_img, support_masks, query_gt=None, r_threshold=0.25):
+        """One denoising step for a batch of episodes, everything on device.
+
+        support_imgs / support_masks [b*s, 3, H, W], query_img [b, 3, H, W] in [-1, 1];
+        query_gt optional uint8 [b, H, W] (0/1, 255 = ignore).
+        Returns dict(z0 [b,4,h,w] fp32, dec [b,3,H,W] fp32 in [-1,1], seg_u8 [b,3,H,W] uint8,
+        counts [b,4] int64 = inter0, inter1, union0, union1 or None).
+        Equivalent to single_infer(num_inference_steps=1) when the scheduler is the reference's
+        degenerate DDIM (z0 = -v); falls back to it otherwise.
+        """
+        sched = self.scheduler
+        sched.set_timesteps(1, device=self.device)
+        t = sched.timesteps[0]
+        if not sched.z0_is_neg_v(t):
+            seg, lat = self.single_infer(support_imgs, query_img, support_masks, return_latents=True)
+            dec = seg / 255.0 * 2.0 - 1.0
+            z0 = lat["z0"]
+        else:
+            b = query_img.shape[0]
+            n_sup = support_imgs.shape[0]
+            # one VAE-encoder launch train for all 2s+1 image groups (weights read once)
+            allimg = torch.cat([support_imgs, support_masks, query_img], dim=0).to(self.device)
+            z_all = self.encode_rgb(allimg)
+            z_ref, z_gt, z_tag = z_all[:n_sup], z_all[n_sup:2 * n_sup], z_all[2 * n_sup:]
+            cond_ref = torch.cat([z_ref, z_gt], dim=1)
+            embed = self.encode_clip_feature().to(self.device)
+            ehs = embed.repeat((b, 1, 1))
+            ehs_ref = ehs.repeat((n_sup // b, 1, 1))
+            tt = t * self.test_timestep
+            self.unet.clear_attn_bank()
+            self.unet(cond_ref, tt, encoder_hidden_states=ehs_ref, is_target=False)
+            z0 = self.unet(z_tag.contiguous(), tt, encoder_hidden_states=ehs, out_scale=-1.0).sample  # z0 = -v
+            self.unet.clear_attn_bank()
+            dec = self.decode_seg(z0)
+        seg_u8, counts = ops.seg_postprocess(dec.contiguous(), query_gt, r_threshold)
+        return dict(z0=z0, dec=dec, seg_u8=seg_u8, counts=counts)
+
+    # ------------------------------------------------------------------ __call__ (P:223-583)
+    @torch.no_grad()
+    def __call__(self, input_images, denoising_steps=10, ensemble_size=10, processing_res=768,
+                 match_input_res=True, batch_size=0, color_map="Spectral", show_progress_bar=True,
+                 ensemble_kwargs=None, mode="depth", rgb_paths=[], seed=None):
+        from PIL import Image
+        if mode == "depth":
+            raise NotImplementedError("only the few-shot segmentation path of DiffewS is implemented")
+        if not match_input_res:
+            assert processing_res is not None
+        assert processing_res >= 0 and denoising_steps >= 1 and ensemble_size >= 1   # P:295-297
+        if not all(torch.is_tensor(t) for t in input_images) or len(input_images) != 3:
+            raise TypeError("input_images must be [support_imgs, query_img, support_masks] tensors (E:106-110)")
+        sup, qry, msk = (t.to(self.device) for t in input_images)
+        lo = torch.stack([t.min() for t in (sup, qry, msk)]).min()
+        hi = torch.stack([t.max() for t in (sup, qry, msk)]).max()
+        assert float(lo) >= -1.0 and float(hi) <= 1.0          # P:309 (one sync instead of six)
+        input_size = tuple(qry.shape[-2:])                      # P:307
+        bs_imgs = qry.shape[0]                                  # P:308
+        s = sup.shape[0] // bs_imgs
+        inner = batch_size if batch_size and batch_size > 0 else bs_imgs
+        preds = []
+        for i0 in range(0, bs_imgs, inner):                     # P:425-442 (explicit batch, no VRAM table)
+            i1 = min(bs_imgs, i0 + inner)
+            if denoising_steps == 1:
+                r = self.run_episodes(sup[i0 * s:i1 * s], qry[i0:i1], msk[i0 * s:i1 * s])
+                seg = (r["dec"] * 0.5 + 0.5) * 255              # P:790-795
+            else:
+                seg = self.single_infer(sup[i0 * s:i1 * s], qry[i0:i1], msk[i0 * s:i1 * s],
+                                        num_inference_steps=denoising_steps)
+            preds.append(seg)
+        one = torch.cat(preds, dim=0)                           # [bs_imgs, 3, H, W]
+        # the episode is deterministic (no noise is drawn, P:675), so the ensemble members are equal
+        depth_preds = torch.stack([one] * ensemble_size).mean(dim=0)   # P:446, 468
+        if match_input_res and tuple(depth_preds.shape[-2:]) != input_size:
+            depth_preds = F.interpolate(depth_preds, input_size, mode="nearest")   # P:474
+        seg_colored = depth_preds.clip(0, 255).cpu().numpy().astype(np.uint8)       # P:534
+        imgs = [Image.fromarray(chw2hwc(seg_colored[i])).resize((input_size[1], input_size[0]))
+                for i in range(seg_colored.shape[0])]                               # P:537-540
+        return MarigoldSegOutput(seg_colored=imgs[0] if len(imgs) == 1 else imgs, uncertainty=None)
+
+
+MarigoldPipeline = MarigoldPipelineRGBLatentNoise  # alias used by evaluation_util/main_oss.py:24

@@ -1,0 +1,336 @@
+"""MI355X engine behind the reference's two-input UNet.
+
+Drop-in for `MyUNet2DConditionModel`
+(/root/reference/diffews/models/unet_2d_condition.py): same constructor config keys
+(U:185-241), `from_pretrained(path, subfolder=)` (evaluation_util/main_oss.py:338-345),
+`forward(sample, timestep, encoder_hidden_states, is_target=True, ..., return_dict=True)`
+(U:879-895) and `clear_attn_bank()` (U:656-664), with the K/V-bank semantics of `MyAttention`
+(diffews/models/attention_processor.py:41-50, 251-267): the first forward after
+`clear_attn_bank()` stores every self-attention layer's K/V, the next forward attends over
+`[K_own ; K_bank]` with the n-shot batch->token fold of the xformers processor.
+
+All compute is hand-written HIP (diffews_amd/csrc) through the C ABI; activations live in HBM as
+NHWC storage-dtype tensors, so the NCHW<->token permutes of Transformer2DModel vanish.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+from . import ops, packing, weights
+
+
+@dataclass
+class UNet2DConditionOutput:
+    """Mirror of the reference's output dataclass (U:61-71)."""
+    sample: torch.Tensor = None
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class _Resnet:
+    def __init__(self, sd, p, dev, dt, eps, groups):
+        g = lambda k: sd[p + k]
+        self.eps, self.groups = eps, groups
+        self.g1, self.b1 = g("norm1.weight").float().to(dev), g("norm1.bias").float().to(dev)
+        self.g2, self.b2 = g("norm2.weight").float().to(dev), g("norm2.bias").float().to(dev)
+        self.cout = g("conv1.weight").shape[0]
+        self.w1 = packing.pack_conv3x3(g("conv1.weight")).to(dev, dt)
+        self.cb1 = g("conv1.bias").float().to(dev)
+        self.w2 = packing.pack_conv3x3(g("conv2.weight")).to(dev, dt)
+        self.cb2 = g("conv2.bias").float().to(dev)
+        self.ws = None
+        if p + "conv_shortcut.weight" in sd:
+            self.ws = packing.pack_conv1x1(g("conv_shortcut.weight")).to(dev, dt)
+            self.bs = g("conv_shortcut.bias").float().to(dev)
+        self.has_temb = p + "time_emb_proj.weight" in sd
+        self.temb_slice = None  # (offset, cout) into the fused time-projection output
+
+    def __call__(self, x, tproj=None):
+        B, H, W, Cin = x.shape
+        h = ops.groupnorm(x, self.g1, self.b1, self.groups, self.eps, silu=True)
+        rb = None
+        if self.has_temb:
+            o, c = self.temb_slice
+            rb = tproj[:, o:o + c]
+        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1, rowbias=rb)
+        h = ops.groupnorm(h, self.g2, self.b2, self.groups, self.eps, silu=True)
+        sc = x
+        if self.ws is not None:
+            sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
+        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc)
+
+
+class _Transformer:
+    """Transformer2DModel(use_linear_projection) with one BasicTransformerBlock; owns the bank."""
+
+    def __init__(self, sd, p, dev, dt, heads, groups):
+        g = lambda k: sd[p + k]
+        f = lambda k: g(k).float().to(dev)
+        w = lambda k: g(k).to(dev, dt).contiguous()
+        self.heads, self.groups = heads, groups
+        self.gn_g, self.gn_b = f("norm.weight"), f("norm.bias")
+        self.w_in, self.b_in = w("proj_in.weight"), f("proj_in.bias")
+        self.w_out, self.b_out = w("proj_out.weight"), f("proj_out.bias")
+        b = "transformer_blocks.0."
+        self.ln = [(f(b + n + ".weight"), f(b + n + ".bias")) for n in ("norm1", "norm2", "norm3")]
+        self.w_qkv = torch.cat([g(b + "attn1.to_q.weight"), g(b + "attn1.to_k.weight"),
+                                g(b + "attn1.to_v.weight")], 0).to(dev, dt).contiguous()
+        self.w_o1, self.b_o1 = w(b + "attn1.to_out.0.weight"), f(b + "attn1.to_out.0.bias")
+        self.w_q2 = w(b + "attn2.to_q.weight")
+        self.w_kv2 = torch.cat([g(b + "attn2.to_k.weight"), g(b + "attn2.to_v.weight")], 0).to(dev, dt).contiguous()
+        self.w_o2, self.b_o2 = w(b + "attn2.to_out.0.weight"), f(b + "attn2.to_out.0.bias")
+        wp, bp = packing.pack_geglu(g(b + "ff.net.0.proj.weight"), g(b + "ff.net.0.proj.bias"))
+        self.w_ff1, self.b_ff1 = wp.to(dev, dt), bp.to(dev)
+        self.w_ff2, self.b_ff2 = w(b + "ff.net.2.weight"), f(b + "ff.net.2.bias")
+        self.k_bank = None
+        self.v_bank = None
+
+    def clear_bank(self):
+        self.k_bank = None
+        self.v_bank = None
+
+    def __call__(self, x, ehs2d, L_ctx):
+        B, H, W, C = x.shape
+        N = H * W
+        heads = self.heads
+        n = ops.groupnorm(x, self.gn_g, self.gn_b, self.groups, 1e-6, silu=False)
+        t = ops.linear(n.view(-1, C), self.w_in, bias=self.b_in)
+        # --- attn1: KV-fusion self-attention (A:237-271)
+        ln = ops.layernorm(t, *self.ln[0])
+        qkv = ops.linear(ln, self.w_qkv).view(B, N, 3 * C)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        if self.k_bank is None:  # A:251-252 / 260-261: first pass after clear fills the bank
+            self.k_bank, self.v_bank = k, v
+            att = ops.fsa_attention(q, k, v, heads)
+        else:                    # A:253-258 / 262-267: [own ; bank], ref batch folded into tokens
+            bank_b = self.k_bank.shape[0]
+            if bank_b % B != 0:
+                raise ValueError(f"bank holds {bank_b} support images, not a multiple of the query batch {B}")
+            att = ops.fsa_attention(q, k, v, heads, self.k_bank, self.v_bank, nshot=bank_b // B)
+        t = ops.linear(att.view(-1, C), self.w_o1, bias=self.b_o1, residual=t)
+        # --- attn2: cross-attention on the prompt tokens
+        ln = ops.layernorm(t, *self.ln[1])
+        q2 = ops.linear(ln, self.w_q2).view(B, N, C)
+        kv2 = ops.linear(ehs2d, self.w_kv2).view(B, L_ctx, 2 * C)
+        ca = ops.cross_attention(q2, kv2[..., :C], kv2[..., C:], heads)
+        t = ops.linear(ca.view(-1, C), self.w_o2, bias=self.b_o2, residual=t)
+        # --- GEGLU feed-forward
+        ln = ops.layernorm(t, *self.ln[2])
+        ff = ops.linear(ln, self.w_ff1, bias=self.b_ff1, geglu=True)
+        t = ops.linear(ff, self.w_ff2, bias=self.b_ff2, residual=t)
+        return ops.linear(t, self.w_out, bias=self.b_out, residual=x.view(-1, C)).view(B, H, W, C)
+
+
+class _Conv:
+    def __init__(self, sd, p, dev, dt):
+        self.w = packing.pack_conv3x3(sd[p + "weight"]).to(dev, dt)
+        self.b = sd[p + "bias"].float().to(dev)
+        self.cout = sd[p + "weight"].shape[0]
+
+
+class MyUNet2DConditionModel:
+    """HIP engine with the reference UNet's interface.  Inference only (round 1)."""
+
+    def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", **kwargs):
+        cfg = weights.default_unet_config()
+        cfg.update(config or {})
+        cfg.update(kwargs)
+        self.config = _Cfg(cfg)
+        if torch_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("engine storage dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = torch_dtype
+        self.device = torch.device(device)
+        L.lib()  # fail loudly right here if the HIP library is not built
+        if state_dict is None:
+            raise ValueError("MyUNet2DConditionModel needs a state_dict (use from_pretrained / synthetic weights)")
+        weights.check_state_dict(state_dict, weights.unet_param_shapes(cfg), "unet")
+        self._build(state_dict)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, revision=None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+        cfg = weights.load_config(path, subfolder)
+        sd = weights.load_state_dict(path, subfolder)
+        return cls(cfg, sd, torch_dtype=torch_dtype, device=device)
+
+    def save_pretrained(self, path, subfolder=None):
+        weights.save_pretrained(path, dict(self.config), self._sd_cpu, subfolder)
+
+    def _build(self, sd):
+        cfg, dev, dt = self.config, self.device, self.dtype
+        self._sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+        boc = list(cfg["block_out_channels"])
+        heads = cfg["attention_head_dim"]
+        heads = [heads] * len(boc) if isinstance(heads, int) else list(heads)
+        for c, h in zip(boc, heads):
+            if c % 64 or c // h != 64:
+                raise ValueError("gfx950 kernels need channel counts that are multiples of 64 and head_dim 64")
+        groups, eps, lpb = cfg["norm_num_groups"], cfg["norm_eps"], cfg["layers_per_block"]
+        self.groups, self.eps = groups, eps
+        # boundary convs (Cin <= 8): fp32 weights for the direct kernel
+        self.w_in = packing.pack_conv_small(sd["conv_in.weight"]).to(dev)
+        self.b_in = sd["conv_in.bias"].float().to(dev)
+        self.w_in_ref = packing.pack_conv_small(sd["conv_in_ref.weight"]).to(dev)
+        self.b_in_ref = sd["conv_in_ref.bias"].float().to(dev)
+        self.te_w1 = sd["time_embedding.linear_1.weight"].to(dev, dt).contiguous()
+        self.te_b1 = sd["time_embedding.linear_1.bias"].float().to(dev)
+        self.te_w2 = sd["time_embedding.linear_2.weight"].to(dev, dt).contiguous()
+        self.te_b2 = sd["time_embedding.linear_2.bias"].float().to(dev)
+        R = lambda p: _Resnet(sd, p, dev, dt, eps, groups)
+        T = lambda p, h: _Transformer(sd, p, dev, dt, h, groups)
+        self.down = []
+        for i, typ in enumerate(cfg["down_block_types"]):
+            blk = dict(res=[R(f"down_blocks.{i}.resnets.{j}.") for j in range(lpb)], attn=None, down=None)
+            if typ == "CrossAttnDownBlock2D":
+                blk["attn"] = [T(f"down_blocks.{i}.attentions.{j}.", heads[i]) for j in range(lpb)]
+            if i != len(boc) - 1:
+                blk["down"] = _Conv(sd, f"down_blocks.{i}.downsamplers.0.conv.", dev, dt)
+            self.down.append(blk)
+        self.mid = dict(res=[R("mid_block.resnets.0."), R("mid_block.resnets.1.")],
+                        attn=T("mid_block.attentions.0.", heads[-1]))
+        rheads = heads[::-1]
+        self.up = []
+        for i, typ in enumerate(cfg["up_block_types"]):
+            blk = dict(res=[R(f"up_blocks.{i}.resnets.{j}.") for j in range(lpb + 1)], attn=None, up=None)
+            if typ == "CrossAttnUpBlock2D":
+                blk["attn"] = [T(f"up_blocks.{i}.attentions.{j}.", rheads[i]) for j in range(lpb + 1)]
+            if i != len(boc) - 1:
+                blk["up"] = _Conv(sd, f"up_blocks.{i}.upsamplers.0.conv.", dev, dt)
+            self.up.append(blk)
+        self.gn_out = (sd["conv_norm_out.weight"].float().to(dev), sd["conv_norm_out.bias"].float().to(dev))
+        self.conv_out = _Conv(sd, "conv_out.", dev, dt)
+        # all 22 time_emb_proj layers fused into one GEMM: [sum(Cout), temb]
+        ws, bs, off = [], [], 0
+        for r, p in self._resnets_with_prefix():
+            ws.append(sd[p + "time_emb_proj.weight"])
+            bs.append(sd[p + "time_emb_proj.bias"])
+            r.temb_slice = (off, r.cout)
+            off += r.cout
+        self.tp_w = torch.cat(ws, 0).to(dev, dt).contiguous()
+        self.tp_b = torch.cat(bs, 0).float().to(dev)
+
+    def _resnets_with_prefix(self):
+        for i, blk in enumerate(self.down):
+            for j, r in enumerate(blk["res"]):
+                yield r, f"down_blocks.{i}.resnets.{j}."
+        yield self.mid["res"][0], "mid_block.resnets.0."
+        yield self.mid["res"][1], "mid_block.resnets.1."
+        for i, blk in enumerate(self.up):
+            for j, r in enumerate(blk["res"]):
+                yield r, f"up_blocks.{i}.resnets.{j}."
+
+    def _transformers(self):
+        for blk in self.down + self.up:
+            for t in blk["attn"] or []:
+                yield t
+        yield self.mid["attn"]
+
+    # ------------------------------------------------------------------ reference API
+    def clear_attn_bank(self):
+        for t in self._transformers():
+            t.clear_bank()
+
+    def to(self, device=None, dtype=None):
+        if dtype is not None and dtype != self.dtype or device is not None and torch.device(device) != self.device:
+            self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
+                          device=device or self.device)
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None  # the HIP attention kernel is always the memory-efficient one
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, is_target=True, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None,
+                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True,
+                out_scale=1.0):
+        for name, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
+                        ("attention_mask", attention_mask), ("added_cond_kwargs", added_cond_kwargs),
+                        ("down_block_additional_residuals", down_block_additional_residuals),
+                        ("mid_block_additional_residual", mid_block_additional_residual),
+                        ("down_intrablock_additional_residuals", down_intrablock_additional_residuals),
+                        ("encoder_attention_mask", encoder_attention_mask)):
+            if v is not None:
+                raise NotImplementedError(f"{name} is not on the DiffewS hot path (always None there)")
+        cfg, dt, dev = self.config, self.dtype, self.device
+        in_dtype = sample.dtype
+        x_in = sample.to(device=dev, dtype=torch.float32).contiguous()
+        B, Cin, h, w = x_in.shape
+        if (h % 8 or w % 8) and False:
+            raise ValueError("latent size must be divisible by 8")
+        # ---- 1. time (U:991-1015)
+        if not torch.is_tensor(timestep):
+            t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
+        else:
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        c0 = cfg["block_out_channels"][0]
+        temb = ops.timestep_embedding(t, c0, dt, cfg["flip_sin_to_cos"], float(cfg["freq_shift"]))
+        e = ops.linear(temb, self.te_w1, bias=self.te_b1, act=L.ACT_SILU)
+        semb = ops.linear(e, self.te_w2, bias=self.te_b2, act=L.ACT_SILU)  # silu(emb): every consumer applies it
+        tproj = ops.linear(semb, self.tp_w, bias=self.tp_b, out_f32=True)  # [B, sum Cout] fp32
+        # ---- prompt tokens
+        ehs = encoder_hidden_states.to(device=dev, dtype=dt)
+        if ehs.shape[0] != B:
+            raise ValueError("encoder_hidden_states batch must match sample batch")
+        L_ctx = ehs.shape[1]
+        ehs2d = ehs.reshape(B * L_ctx, ehs.shape[2]).contiguous()
+        # ---- 2. conv_in | conv_in_ref (U:1117-1121)
+        if is_target:
+            if Cin != cfg["in_channels"]:
+                raise ValueError(f"target pass expects {cfg['in_channels']} channels, got {Cin}")
+            x = ops.conv_small(x_in, self.w_in, self.b_in, c0, 9, dt)
+        else:
+            if Cin != cfg["in_channels_ref"]:
+                raise ValueError(f"support pass expects {cfg['in_channels_ref']} channels, got {Cin}")
+            x = ops.conv_small(x_in, self.w_in_ref, self.b_in_ref, c0, 9, dt)
+        # ---- 3. down (U:1153-1175)
+        skips = [x]
+        for blk in self.down:
+            for j, r in enumerate(blk["res"]):
+                x = r(x, tproj)
+                if blk["attn"] is not None:
+                    x = blk["attn"][j](x, ehs2d, L_ctx)
+                skips.append(x)
+            if blk["down"] is not None:
+                d = blk["down"]
+                x = ops.conv3x3(x, d.w, d.cout, bias=d.b, stride=2, pad=1)
+                skips.append(x)
+        # ---- 4. mid (U:1189-1198)
+        x = self.mid["res"][0](x, tproj)
+        x = self.mid["attn"](x, ehs2d, L_ctx)
+        x = self.mid["res"][1](x, tproj)
+        # ---- 5. up (U:1214-1243)
+        for blk in self.up:
+            for j, r in enumerate(blk["res"]):
+                x = ops.concat_channels(x, skips.pop())
+                x = r(x, tproj)
+                if blk["attn"] is not None:
+                    x = blk["attn"][j](x, ehs2d, L_ctx)
+            if blk["up"] is not None:
+                u = blk["up"]
+                x = ops.conv3x3(x, u.w, u.cout, bias=u.b, ups=True)
+        # ---- 6. out (U:1246-1249); out_scale lets the pipeline fold z0 = -v into the epilogue
+        x = ops.groupnorm(x, *self.gn_out, self.groups, self.eps, silu=True)
+        co = self.conv_out
+        out = ops.conv3x3(x, co.w, co.cout, bias=co.b, out_nchw_f32=True, out_scale=out_scale)
+        if in_dtype in (torch.float16, torch.bfloat16, torch.float64):
+            out = out.to(in_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+
+CustomUNet2DConditionModel = MyUNet2DConditionModel  # name used by evaluation_util/main_oss.py:27

@@ -1,0 +1,228 @@
+"""MI355X engine behind diffusers' AutoencoderKL as the reference pipeline drives it:
+`vae.encoder(x)` + `vae.quant_conv(h)` (marigold_pipeline_rgb_latent_noise.py:852-853) and
+`vae.post_quant_conv(z)` + `vae.decoder(z)` (P:901-902); also `encode(x).latent_dist` for the
+training launcher (train_icl_multitask_nocrop_nearest_nshot_v3.py:1347).
+
+Boundary tensors are NCHW fp32 like the reference's; inside, activations are NHWC storage dtype.
+"""
+import torch
+
+from . import _lib as L
+from . import ops, packing, weights
+from .unet import _Cfg, _Conv
+
+
+class _VaeResnet:
+    def __init__(self, sd, p, dev, dt, groups):
+        g = lambda k: sd[p + k]
+        self.groups = groups
+        self.g1, self.b1 = g("norm1.weight").float().to(dev), g("norm1.bias").float().to(dev)
+        self.g2, self.b2 = g("norm2.weight").float().to(dev), g("norm2.bias").float().to(dev)
+        self.cout = g("conv1.weight").shape[0]
+        self.w1 = packing.pack_conv3x3(g("conv1.weight")).to(dev, dt)
+        self.cb1 = g("conv1.bias").float().to(dev)
+        self.w2 = packing.pack_conv3x3(g("conv2.weight")).to(dev, dt)
+        self.cb2 = g("conv2.bias").float().to(dev)
+        self.ws = None
+        if p + "conv_shortcut.weight" in sd:
+            self.ws = packing.pack_conv1x1(g("conv_shortcut.weight")).to(dev, dt)
+            self.bs = g("conv_shortcut.bias").float().to(dev)
+
+    def __call__(self, x):
+        B, H, W, Cin = x.shape
+        h = ops.groupnorm(x, self.g1, self.b1, self.groups, 1e-6, silu=True)
+        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1)
+        h = ops.groupnorm(h, self.g2, self.b2, self.groups, 1e-6, silu=True)
+        sc = x
+        if self.ws is not None:
+            sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
+        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc)
+
+
+class _VaeAttention:
+    """Mid-block attention: GN -> biased q/k/v -> 1 head of dim C -> out proj -> + residual."""
+
+    def __init__(self, sd, p, dev, dt, groups):
+        f = lambda k: sd[p + k].float().to(dev)
+        w = lambda k: sd[p + k].to(dev, dt).contiguous()
+        self.groups = groups
+        self.gn = (f("group_norm.weight"), f("group_norm.bias"))
+        self.wq, self.bq = w("to_q.weight"), f("to_q.bias")
+        self.wk, self.bk = w("to_k.weight"), f("to_k.bias")
+        self.wv, self.bv = w("to_v.weight"), f("to_v.bias")
+        self.wo, self.bo = w("to_out.0.weight"), f("to_out.0.bias")
+
+    def __call__(self, x):
+        B, H, W, C = x.shape
+        N = H * W
+        n = ops.groupnorm(x, *self.gn, self.groups, 1e-6, silu=False).view(-1, C)
+        q = ops.linear(n, self.wq, bias=self.bq).view(B, N, C)
+        k = ops.linear(n, self.wk, bias=self.bk).view(B, N, C)
+        v = ops.linear(n, self.wv, bias=self.bv).view(B, N, C)
+        s = ops.bmm_nt(q, k, out_f32=True)                       # [B, N, N] fp32 scores
+        p = ops.softmax_rows(s, x.dtype, scale=C ** -0.5)        # upcast softmax, storage-dtype probs
+        o = ops.bmm_nt(p, ops.transpose(v))                      # [B, N, C]
+        return ops.linear(o.view(-1, C), self.wo, bias=self.bo, residual=x.view(-1, C)).view(B, H, W, C)
+
+
+class _Mid:
+    def __init__(self, sd, p, dev, dt, groups):
+        self.r0 = _VaeResnet(sd, p + "resnets.0.", dev, dt, groups)
+        self.att = _VaeAttention(sd, p + "attentions.0.", dev, dt, groups)
+        self.r1 = _VaeResnet(sd, p + "resnets.1.", dev, dt, groups)
+
+    def __call__(self, x):
+        return self.r1(self.att(self.r0(x)))
+
+
+class _Encoder:
+    def __init__(self, vae, sd):
+        cfg, dev, dt, g = vae.config, vae.device, vae.dtype, vae.config["norm_num_groups"]
+        self.dt, self.groups = dt, g
+        boc, lpb = list(cfg["block_out_channels"]), cfg["layers_per_block"]
+        self.c0 = boc[0]
+        self.w_in = packing.pack_conv_small(sd["encoder.conv_in.weight"]).to(dev)
+        self.b_in = sd["encoder.conv_in.bias"].float().to(dev)
+        self.blocks = []
+        for i in range(len(boc)):
+            res = [_VaeResnet(sd, f"encoder.down_blocks.{i}.resnets.{j}.", dev, dt, g) for j in range(lpb)]
+            down = _Conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv.", dev, dt) if i != len(boc) - 1 else None
+            self.blocks.append((res, down))
+        self.mid = _Mid(sd, "encoder.mid_block.", dev, dt, g)
+        self.gn_out = (sd["encoder.conv_norm_out.weight"].float().to(dev),
+                       sd["encoder.conv_norm_out.bias"].float().to(dev))
+        self.conv_out = _Conv(sd, "encoder.conv_out.", dev, dt)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        x = x.to(dtype=torch.float32).contiguous()
+        h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt)
+        for res, down in self.blocks:
+            for r in res:
+                h = r(h)
+            if down is not None:  # F.pad(0,1,0,1) + conv stride 2 padding 0
+                h = ops.conv3x3(h, down.w, down.cout, bias=down.b, stride=2, pad=0)
+        h = self.mid(h)
+        h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
+        co = self.conv_out
+        return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True)  # [n, 2*lc, h, w] fp32
+
+
+class _Decoder:
+    def __init__(self, vae, sd):
+        cfg, dev, dt, g = vae.config, vae.device, vae.dtype, vae.config["norm_num_groups"]
+        self.dt, self.groups = dt, g
+        boc, lpb = list(cfg["block_out_channels"]), cfg["layers_per_block"]
+        rboc = boc[::-1]
+        self.c0 = rboc[0]
+        self.w_in = packing.pack_conv_small(sd["decoder.conv_in.weight"]).to(dev)
+        self.b_in = sd["decoder.conv_in.bias"].float().to(dev)
+        self.mid = _Mid(sd, "decoder.mid_block.", dev, dt, g)
+        self.blocks = []
+        for i in range(len(boc)):
+            res = [_VaeResnet(sd, f"decoder.up_blocks.{i}.resnets.{j}.", dev, dt, g) for j in range(lpb + 1)]
+            up = _Conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv.", dev, dt) if i != len(boc) - 1 else None
+            self.blocks.append((res, up))
+        self.gn_out = (sd["decoder.conv_norm_out.weight"].float().to(dev),
+                       sd["decoder.conv_norm_out.bias"].float().to(dev))
+        self.conv_out = _Conv(sd, "decoder.conv_out.", dev, dt)
+
+    @torch.no_grad()
+    def __call__(self, z):
+        z = z.to(dtype=torch.float32).contiguous()
+        h = ops.conv_small(z, self.w_in, self.b_in, self.c0, 9, self.dt)
+        h = self.mid(h)
+        for res, up in self.blocks:
+            for r in res:
+                h = r(h)
+            if up is not None:
+                h = ops.conv3x3(h, up.w, up.cout, bias=up.b, ups=True)
+        h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
+        co = self.conv_out
+        return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True)  # [b, 3, H, W] fp32
+
+
+class _Conv1x1Boundary:
+    """quant_conv / post_quant_conv: 1x1 conv on NCHW fp32 latents."""
+
+    def __init__(self, sd, p, dev, dt):
+        self.w = packing.pack_conv_small(sd[p + "weight"]).to(dev)
+        self.b = sd[p + "bias"].float().to(dev)
+        self.cout, self.dt = sd[p + "weight"].shape[0], dt
+
+    @torch.no_grad()
+    def __call__(self, x, in_scale=1.0, out_scale=1.0):
+        return ops.conv_small(x.to(dtype=torch.float32).contiguous(), self.w, self.b, self.cout, 1, self.dt,
+                              nchw_f32_out=True, in_scale=in_scale, out_scale=out_scale)
+
+
+class _DiagonalGaussian:
+    def __init__(self, moments):
+        self.mean, self.logvar = torch.chunk(moments, 2, dim=1)
+        self.logvar = self.logvar.clamp(-30.0, 20.0)
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + torch.exp(0.5 * self.logvar) * noise
+
+
+class _EncOut:
+    def __init__(self, dist):
+        self.latent_dist = dist
+
+
+class AutoencoderKL:
+    def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", **kwargs):
+        cfg = weights.default_vae_config()
+        cfg.update(config or {})
+        cfg.update(kwargs)
+        self.config = _Cfg(cfg)
+        if torch_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("engine storage dtype must be torch.bfloat16 or torch.float16")
+        self.dtype, self.device = torch_dtype, torch.device(device)
+        L.lib()
+        if state_dict is None:
+            raise ValueError("AutoencoderKL needs a state_dict (use from_pretrained / synthetic weights)")
+        weights.check_state_dict(state_dict, weights.vae_param_shapes(cfg), "vae")
+        for c in cfg["block_out_channels"]:
+            if c % 64:
+                raise ValueError("gfx950 kernels need VAE channel counts that are multiples of 64")
+        self._sd_cpu = {k: v.detach().cpu() for k, v in state_dict.items()}
+        sd = state_dict
+        self.encoder = _Encoder(self, sd)
+        self.decoder = _Decoder(self, sd)
+        self.quant_conv = _Conv1x1Boundary(sd, "quant_conv.", self.device, self.dtype)
+        self.post_quant_conv = _Conv1x1Boundary(sd, "post_quant_conv.", self.device, self.dtype)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+        return cls(weights.load_config(path, subfolder), weights.load_state_dict(path, subfolder),
+                   torch_dtype=torch_dtype, device=device)
+
+    def save_pretrained(self, path, subfolder=None):
+        weights.save_pretrained(path, dict(self.config), self._sd_cpu, subfolder)
+
+    def to(self, device=None, dtype=None):
+        if dtype is not None and dtype != self.dtype or device is not None and torch.device(device) != self.device:
+            self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
+                          device=device or self.device)
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def encode(self, x):
+        return _EncOut(_DiagonalGaussian(self.quant_conv(self.encoder(x))))
+
+    def decode(self, z):
+        class _Out:
+            pass
+        o = _Out()
+        o.sample = self.decoder(self.post_quant_conv(z))
+        return o

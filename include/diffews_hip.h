@@ -66,6 +66,7 @@ typedef struct {
   int64_t a_elems, w_elems;           /* extent of A / W in elements (for bounds-checked loads) */
   int32_t M, N, K;
   int32_t lda, ldc, ldr;
+  int32_t ld_rowbias;                 /* row stride of rowbias in floats (0 => N) */
   int32_t taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups;
   int32_t rows_per_img;
   float out_scale;
