@@ -65,6 +65,7 @@ SYMBOLS = {
     "dfw_error_string": (C.c_char_p, [_i32]),
     "dfw_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dfw_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
+    "dfw_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _sz]),
     "dfw_fsa_attention": (_i32, [C.POINTER(FsaArgs), _vp]),
     "dfw_cross_attention": (_i32, [C.POINTER(XattnArgs), _vp]),
     "dfw_groupnorm": (_i32, [C.POINTER(GroupNormArgs), _vp]),
@@ -89,6 +90,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the MI355X kernels are not built. Run `python -m diffews_amd.build` "
                 "(or __graft_entry__.build()). There is no CPU / PyTorch fallback.")
+        # torch must be loaded first: it ships its own libamdhip64 and the kernels here run on
+        # torch's streams, so both have to bind to the SAME HIP runtime instance (loading this
+        # library first pulls /opt/rocm's copy in and the process ends up with no visible device).
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(h, name)

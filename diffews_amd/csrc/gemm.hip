@@ -14,6 +14,7 @@
 // barrier per K-step.  All global loads are bounds-checked buffer loads, so conv halos, ragged
 // M tiles and N padding read as zero with no divergent branches.
 #include "common.h"
+#include <stdio.h>
 
 namespace dfw {
 
@@ -332,16 +333,24 @@ static int launch_tile(const GemmP& p, hipStream_t st) {
   return 0;
 }
 
+// Tile choice: the 128x128 tile has the best MFMA:load ratio; fall back to narrower tiles when
+// it would leave most of the 256 CUs idle or waste half a tile on N padding.
+static void pick_tile(const GemmP& p, int& bm, int& bn) {
+  const long long z = p.batch > 1 ? p.batch : p.splitk;
+  const bool n128 = (p.N % 128) == 0 || p.N >= 1024;
+  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * z;
+  const long long t64 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * z;
+  if (p.geglu || (p.M >= 128 && n128 && t128 >= 192)) { bm = 128; bn = 128; }
+  else if (p.M >= 128 && t64 >= 192) { bm = 128; bn = 64; }
+  else { bm = 64; bn = 64; }
+}
+
 template <typename T>
 static int launch_gemm(const GemmP& p, hipStream_t st) {
-  // Tile choice: the 128x128 tile has the best MFMA:load ratio; fall back to narrower tiles when
-  // it would leave most of the 256 CUs idle or waste half a tile on N padding.
-  const bool n128 = (p.N % 128) == 0 || p.N >= 1024;
-  if (p.geglu) return launch_tile<T, 128, 128>(p, st);
-  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 1 ? p.batch : p.splitk);
-  if (p.M >= 128 && n128 && t128 >= 192) return launch_tile<T, 128, 128>(p, st);
-  if (p.M >= 128 && (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * (p.batch > 1 ? p.batch : p.splitk) >= 192)
-    return launch_tile<T, 128, 64>(p, st);
+  int bm, bn;
+  pick_tile(p, bm, bn);
+  if (bm == 128 && bn == 128) return launch_tile<T, 128, 128>(p, st);
+  if (bm == 128) return launch_tile<T, 128, 64>(p, st);
   return launch_tile<T, 64, 64>(p, st);
 }
 
@@ -394,6 +403,19 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
   if (p.splitk > p.nk) p.splitk = p.nk;
+  return 0;
+}
+
+extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n) {
+  GemmP p;
+  int esz;
+  int rc = fill_params(a, p, esz);
+  if (rc) return rc;
+  if (!buf || n == 0) return DFW_EINVAL;
+  int bm, bn;
+  pick_tile(p, bm, bn);
+  snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", bm, bn,
+           a->taps == 9 ? "conv" : "lin");
   return 0;
 }
 

@@ -11,7 +11,7 @@ namespace dfw {
 // the channels of each group in a fixed order and writes one (sum, sumsq) pair per group:
 // part[b][chunk][g][2].
 struct GnP {
-  const char* x; char* y; const float* gamma; const float* beta; float* part;
+  const char* x; char* y; const float* gamma; const float* beta; float* part; float* mr;
   int B, HW, C, groups, ldx, ldy, chunks, ppc;  // ppc = pixels per chunk
   float eps;
   int silu;
@@ -55,46 +55,51 @@ __global__ void gn_stats_kernel(const GnP p) {
   }
 }
 
-// Apply: each block first combines the chunk partials of its image in fp64 (fixed order) into
-// per-channel scale/shift in LDS, then streams its pixel range.
-template <typename T>
-__global__ void gn_apply_kernel(const GnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_n[];
-  float* sc = (float*)smem_n;   // [C]
-  float* sh = sc + p.C;         // [C]
-  float* gm = sh + p.C;         // [groups][2] mean, rstd
-  const int b = blockIdx.y;
-  const int cpg = p.C / p.groups;
-  for (int g = threadIdx.x; g < p.groups; g += blockDim.x) {
-    double a = 0.0, a2 = 0.0;
-    for (int ch = 0; ch < p.chunks; ++ch) {
-      const float* o = p.part + (((size_t)b * p.chunks + ch) * p.groups + g) * 2;
-      a += (double)o[0];
-      a2 += (double)o[1];
-    }
-    const double n = (double)p.HW * cpg;
+// Finalize: one wave per (image, group) folds the chunk partials in fp64 (lane-strided, then a fixed
+// butterfly) into mean / rstd: mr[b][g][2].
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
+  const int lane = threadIdx.x & 63;
+  const int bg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bg >= p.B * p.groups) return;
+  const int b = bg / p.groups, g = bg - b * p.groups;
+  double a = 0.0, a2 = 0.0;
+  for (int ch = lane; ch < p.chunks; ch += 64) {
+    const float* o = p.part + (((size_t)b * p.chunks + ch) * p.groups + g) * 2;
+    a += (double)o[0];
+    a2 += (double)o[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    a2 += __shfl_xor(a2, o, 64);
+  }
+  if (lane == 0) {
+    const double n = (double)p.HW * (p.C / p.groups);
     const double mean = a / n;
     double var = a2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    gm[g * 2 + 0] = (float)mean;
-    gm[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    p.mr[bg * 2 + 0] = (float)mean;
+    p.mr[bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float w = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
-    const float r = gm[g * 2 + 1] * w;
-    sc[c] = r;
-    sh[c] = bb - gm[g * 2 + 0] * r;
-  }
-  __syncthreads();
+}
+
+// Apply: thread = fixed 8 channels (scale/shift in registers), streams its pixel range.
+template <typename T>
+__global__ void gn_apply_kernel(const GnP p) {
+  const int b = blockIdx.y;
+  const int cpg = p.C / p.groups;
   const int tpp = p.C >> 3, slots = blockDim.x / tpp;
   const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
   const int p0 = blockIdx.x * p.ppc, p1 = min(p.HW, p0 + p.ppc);
-  if (slot >= slots) return;
   float rs[8], rh[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { rs[i] = sc[cc * 8 + i]; rh[i] = sh[cc * 8 + i]; }
+  for (int i = 0; i < 8; ++i) {
+    const int c = cc * 8 + i, g = c / cpg;
+    const float mean = p.mr[(b * p.groups + g) * 2], rstd = p.mr[(b * p.groups + g) * 2 + 1];
+    const float w = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+    rs[i] = rstd * w;
+    rh[i] = bb - mean * rs[i];
+  }
   const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
   char* yb = p.y + ((size_t)b * p.HW * p.ldy + cc * 8) * sizeof(T);
   for (int px = p0 + slot; px < p1; px += slots) {
@@ -190,7 +195,7 @@ static int gn_geometry(const dfw_groupnorm_args* a, int& chunks, int& ppc, int& 
 extern "C" size_t dfw_groupnorm_workspace_bytes(const dfw_groupnorm_args* a) {
   int chunks, ppc, threads, slots;
   if (gn_geometry(a, chunks, ppc, threads, slots)) return 0;
-  return (size_t)a->B * chunks * a->groups * 2 * sizeof(float);
+  return ((size_t)a->B * chunks * a->groups * 2 + (size_t)a->B * a->groups * 2) * sizeof(float);
 }
 
 extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
@@ -199,25 +204,31 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   if (rc) return rc;
   if (!a->x || !a->y || !a->stats_ws) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
-  if (a->stats_ws_bytes < (size_t)a->B * chunks * a->groups * 2 * sizeof(float)) return DFW_EWORKSPACE;
+  if (a->stats_ws_bytes < ((size_t)a->B * chunks * a->groups * 2 + (size_t)a->B * a->groups * 2) * sizeof(float))
+    return DFW_EWORKSPACE;
   GnP p;
   p.x = (const char*)a->x; p.y = (char*)a->y; p.gamma = a->gamma; p.beta = a->beta;
   p.part = (float*)a->stats_ws;
+  p.mr = p.part + (size_t)a->B * chunks * a->groups * 2;
   p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.ldy = a->ldy;
   p.chunks = chunks; p.ppc = ppc; p.eps = a->eps; p.silu = a->silu;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds1 = (size_t)slots * a->C * 2 * sizeof(float);
-  const size_t lds2 = ((size_t)2 * a->C + 2 * a->groups) * sizeof(float);
-  if (lds1 > 64 * 1024 || lds2 > 64 * 1024) return DFW_ESHAPE;
+  if (lds1 > 64 * 1024) return DFW_ESHAPE;
+  const dim3 gridf((a->B * a->groups + 3) / 4);
   dim3 grid(chunks, a->B);
   if (a->dtype == DFW_BF16) {
     hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), lds2, st, p);
+    hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, p);
   } else {
     hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), lds2, st, p);
+    hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, p);
   }
   DFW_CHECK_LAUNCH();
   return 0;

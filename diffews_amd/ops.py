@@ -52,8 +52,26 @@ def auto_splitk(M, N, K):
     return max(1, min(nk // 4, math.ceil(512 / tiles)))
 
 
+# Optional per-launch timing hook (bench.py roofline leg): when set, every GEMM launch is bracketed
+# by events on the launch stream and reported as hook(kernel_name, flops, start_event, end_event).
+gemm_hook = None
+
+
 def _gemm_call(a):
     lib = L.lib()
+    if gemm_hook is not None:
+        buf = C.create_string_buffer(64)
+        L.check(lib.dfw_gemm_kernel_name(C.byref(a), buf, 64), "dfw_gemm_kernel_name")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _gemm_launch(lib, a)
+        e1.record()
+        gemm_hook(buf.value.decode() + ("+splitk" if a.splitk > 1 else ""), 2.0 * a.M * a.N * a.K * max(1, a.batch), e0, e1)
+        return
+    _gemm_launch(lib, a)
+
+
+def _gemm_launch(lib, a):
     ws = None
     if a.splitk > 1:
         nbytes = lib.dfw_gemm_workspace_bytes(C.byref(a))

@@ -272,6 +272,8 @@ class MyUNet2DConditionModel:
         if (h % 8 or w % 8) and False:
             raise ValueError("latent size must be divisible by 8")
         # ---- 1. time (U:991-1015)
+        if torch.is_tensor(timestep) and timestep.device.type == "cpu" and timestep.numel() == 1:
+            timestep = float(timestep)  # host scalar (scheduler.timesteps lives on the host): no H2D copy
         if not torch.is_tensor(timestep):
             t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
         else:

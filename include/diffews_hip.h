@@ -77,6 +77,9 @@ typedef struct {
 
 int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);
 size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a);
+/* Which kernel instantiation dfw_gemm would launch for these arguments, e.g.
+ * "gemm_kernel<bf16,128,128,conv>" (used by bench.py to attribute time per kernel). */
+int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n);
 
 /*
  * KV-fusion self-attention (the DiffewS-specific op): out = softmax(q [k_own ; k_bank]^T * scale) [v_own ; v_bank]
