@@ -88,18 +88,27 @@ def roofline_pass(step):
     """Instrumented eager pass: every GEMM launch bracketed by events on its launch stream."""
     from diffews_amd import ops
     rec = []
-    ops.gemm_hook = lambda name, flops, e0, e1: rec.append((name, flops, e0, e1))
+    ops.gemm_hook = lambda name, flops, e0, e1, shape=None: rec.append((name, flops, e0, e1, shape))
     try:
         step()
         torch.cuda.synchronize()
     finally:
         ops.gemm_hook = None
-    agg = {}
-    for name, flops, e0, e1 in rec:
+    agg, shapes = {}, {}
+    for name, flops, e0, e1, shape in rec:
+        t = e0.elapsed_time(e1) * 1e-3
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
-        a[2] += e0.elapsed_time(e1) * 1e-3
+        a[2] += t
+        b = shapes.setdefault((name, shape), [0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += flops
+        b[2] += t
+    if os.environ.get("DFW_BENCH_SHAPES"):
+        for (name, shape), (n, fl, t) in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:60]:
+            log(f"[shape] {name:36s} M,N,K,taps,stride,ups,splitk,batch={shape}  x{n:3d}  {t * 1e3:8.3f} ms  "
+                f"{fl / t / 1e12:7.1f} TF/s")
     return agg
 
 

@@ -28,6 +28,7 @@ struct GemmP {
   int act, geglu, out_mode, splitk, batch;
   long long strideA, strideW, strideC;
   int nk, cpt, ntn, ntm;
+  int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
 };
 
 // Epilogue for 4 consecutive output channels n..n+3 of output row m (raw fp32 accumulators in v).
@@ -85,8 +86,14 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
   }
 }
 
+// Tile coordinates of one output tile (uniform per workgroup).
+struct TileC {
+  int m0, n0;                 // first output row (linear tiles) / first output channel
+  int img, oy0, ox0;          // 2-D conv tiles: image and top-left output pixel
+};
+
 template <typename T, int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int WTM = BM / 2, WTN = BN / 2, MB = WTM / 32, NB = WTN / 32;
   constexpr int SA = BM / 32, SW = BN / 32;
   constexpr int BUF = (BM + BN) * 128;
@@ -96,15 +103,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
-  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
-  // XCD a contiguous run of tiles (neighbouring tiles share the A rows / W columns in its L2).
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int tn = bid % p.ntn, tm = bid / p.ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
+  // ---- persistent tile walk.  Workgroup ids round-robin over the 8 XCDs, so XCD x owns the
+  // contiguous tile range [x*Q, (x+1)*Q) and its resident workgroups sweep it together
+  // (neighbouring tiles share A halos / W columns in that XCD's L2).  gridDim.x % 8 == 0.
+  const int ntiles = p.ntm * p.ntn;
+  const int nxb = gridDim.x >> 3, xcd = blockIdx.x & 7;
+  const int Q = (ntiles + 7) >> 3;
+  const int t_end = min(ntiles, (xcd + 1) * Q);
+  int tile = xcd * Q + (blockIdx.x >> 3);
+
   const int z = blockIdx.y;
   int ks0 = 0, ks1 = p.nk;
   const char* Ab = p.A;
@@ -118,53 +125,91 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     ks0 = (int)((long long)z * p.nk / p.splitk);
     ks1 = (int)((long long)(z + 1) * p.nk / p.splitk);
   }
+  if (tile >= t_end || ks0 >= ks1) return;
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wb, p.w_bytes);
 
-  // ---- per-thread staging slots: 16-byte chunk kc of rows (tid>>3) + 32*i
-  const int kc = tid & 7, srow = tid >> 3;
-  uint32_t a_off[SA];       // linear case: byte offset of the row (+chunk), or OOB
-  int a_iy0[SA], a_ix0[SA]; // conv case
+  // tile id -> coordinates.  Conv tiles are 2-D patches of tw x (BM/tw) output pixels so that the
+  // 9 taps of a tile re-read an L2-resident halo instead of 9 shifted copies of a pixel row.
+  auto tile_coords = [&](int t) -> TileC {
+    TileC c;
+    const int tn = t % p.ntn, tm = t / p.ntn;
+    c.m0 = tm * BM;
+    c.n0 = tn * BN;
+    c.img = 0; c.oy0 = 0; c.ox0 = 0;
+    if (CONV && p.tw) {
+      c.img = tm / p.tpi;
+      const int t2 = tm - c.img * p.tpi, tyi = t2 / p.tpr, txi = t2 - tyi * p.tpr;
+      c.oy0 = tyi * (BM >> p.tw_log2);
+      c.ox0 = txi << p.tw_log2;
+    }
+    return c;
+  };
+  // tile row r (0..BM) -> output row m (+ pixel coordinates for conv)
+  auto row_to_m = [&](const TileC& c, int r, int& oy, int& ox, int& img) -> int {
+    if (CONV && p.tw) {
+      oy = c.oy0 + (r >> p.tw_log2);
+      ox = c.ox0 + (r & (p.tw - 1));
+      img = c.img;
+      return (img * p.Ho + oy) * p.Wo + ox;
+    }
+    const int m = c.m0 + r;
+    if constexpr (CONV) {
+      img = m / p.rows_per_img;
+      const int rem = m - img * p.rows_per_img;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
+    return m;
+  };
+
+  // ---- loader state: 16-byte chunk kc of tile rows (tid>>3) + 32*i, for the tile being LOADED
+  // Staging is LDS-DMA (buffer_load ... lds): a wave-instruction writes 1 KiB = 8 tile rows
+  // linearly (lane -> row lane>>3, 16-byte slot lane&7), so the bank swizzle is applied on the
+  // SOURCE side: the thread that fills slot j of a row fetches global chunk j ^ ((row>>1)&7).
+  const int srow = tid >> 3;
+  const int kc = (tid & 7) ^ ((srow >> 1) & 7);
+  uint32_t a_off[SA];       // linear: byte offset of the row (+chunk), or OOB
+  int a_iy0[SA], a_ix0[SA]; // conv
   uint32_t a_pix[SA];
+  uint32_t w_off[SW];
+  int tap = 0, cc = 0;      // conv: tap / channel chunk of the K-step being loaded
+  const unsigned limH = p.ups ? 2 * p.Hi : p.Hi, limW = p.ups ? 2 * p.Wi : p.Wi;
+  const int ush = p.ups ? 1 : 0;
+  auto setup_loader = [&](const TileC& c) {
 #pragma unroll
-  for (int i = 0; i < SA; ++i) {
-    const int m = m0 + srow + 32 * i;
-    if constexpr (!CONV) {
-      a_off[i] = m < p.M ? (uint32_t)(((size_t)m * p.lda + kc * 8) * sizeof(T)) : kOOB;
-    } else {
-      if (m < p.M) {
-        const int img = m / p.rows_per_img, rem = m - img * p.rows_per_img;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_iy0[i] = oy * p.stride - p.pad;
-        a_ix0[i] = ox * p.stride - p.pad;
-        a_pix[i] = (uint32_t)img * (uint32_t)(p.Hi * p.Wi);
+    for (int i = 0; i < SA; ++i) {
+      int oy = 0, ox = 0, img = 0;
+      const int m = row_to_m(c, srow + 32 * i, oy, ox, img);
+      if constexpr (!CONV) {
+        a_off[i] = m < p.M ? (uint32_t)(((size_t)m * p.lda + kc * 8) * sizeof(T)) : kOOB;
       } else {
-        a_iy0[i] = -(1 << 20);
-        a_ix0[i] = 0;
-        a_pix[i] = 0;
+        if (m < p.M) {
+          a_iy0[i] = oy * p.stride - p.pad;
+          a_ix0[i] = ox * p.stride - p.pad;
+          a_pix[i] = (uint32_t)img * (uint32_t)(p.Hi * p.Wi);
+        } else {
+          a_iy0[i] = -(1 << 20);
+          a_ix0[i] = 0;
+          a_pix[i] = 0;
+        }
       }
     }
-  }
-  uint32_t w_off[SW];
 #pragma unroll
-  for (int i = 0; i < SW; ++i) {
-    const int n = n0 + srow + 32 * i;
-    w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
-  }
-  // LDS write addresses (within a buffer)
-  uint32_t lds_wa[SA], lds_ww[SW];
-#pragma unroll
-  for (int i = 0; i < SA; ++i) {
-    const int row = srow + 32 * i;
-    lds_wa[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
-  }
-#pragma unroll
-  for (int i = 0; i < SW; ++i) {
-    const int row = BM + srow + 32 * i;
-    lds_ww[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
-  }
-  // LDS fragment read addresses (k-substep s adds ^ (s<<5))
+    for (int i = 0; i < SW; ++i) {
+      const int n = c.n0 + srow + 32 * i;
+      w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
+    }
+    if constexpr (CONV) {
+      tap = ks0 / p.cpt;
+      cc = ks0 - tap * p.cpt;
+    }
+  };
+
+  // fragment read addresses (k-substep s: ^ (s<<5)); the LDS image is [row][slot] with
+  // slot = chunk ^ ((row>>1)&7): conflict-free ds_read_b128 for 32 rows x one chunk
   uint32_t lds_ra[MB], lds_rw[NB];
+  const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int row = wm * WTM + i * 32 + lr;
@@ -176,62 +221,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     lds_rw[i] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
   }
 
-  i32x4 ga[SA], gw[SW];
-  int tap = 0, cc = 0;  // conv: current tap and channel chunk of the K-step being LOADED
-  if constexpr (CONV) {
-    tap = ks0 / p.cpt;
-    cc = ks0 - tap * p.cpt;
-  }
-  auto issue_loads = [&](int ks) {
+  using lds_ptr_t = __attribute__((address_space(3))) void*;
+  auto dma16 = [&](__amdgpu_buffer_rsrc_t r, uint32_t off, char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+  };
+  // issue the LDS-DMA of K-step ks into buffer `buf` (8 rows x 128 B per wave-instruction)
+  auto issue_loads = [&](int ks, char* buf) {
+    char* dst = buf + wave_lds;
     if constexpr (!CONV) {
 #pragma unroll
-      for (int i = 0; i < SA; ++i) ga[i] = buf_load16(ra, a_off[i] + (uint32_t)ks * 128u);
+      for (int i = 0; i < SA; ++i) dma16(ra, a_off[i] + (uint32_t)ks * 128u, dst + i * 4096);
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
       const uint32_t coff = (uint32_t)(cc * 64 + kc * 8);
 #pragma unroll
       for (int i = 0; i < SA; ++i) {
         int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-        bool ok;
-        if (p.ups) {
-          ok = (unsigned)iy < (unsigned)(2 * p.Hi) && (unsigned)ix < (unsigned)(2 * p.Wi);
-          iy >>= 1;
-          ix >>= 1;
-        } else {
-          ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        }
+        const bool ok = (unsigned)iy < limH && (unsigned)ix < limW;
+        iy >>= ush;
+        ix >>= ush;
         const uint32_t off = ((a_pix[i] + (uint32_t)(iy * p.Wi + ix)) * (uint32_t)p.lda + coff) * (uint32_t)sizeof(T);
-        ga[i] = buf_load16(ra, ok ? off : kOOB);
+        dma16(ra, ok ? off : kOOB, dst + i * 4096);   // out-of-range lanes write zeros (halo / padding)
       }
       if (++cc == p.cpt) { cc = 0; ++tap; }
     }
 #pragma unroll
-    for (int i = 0; i < SW; ++i) gw[i] = buf_load16(rw, w_off[i] + (uint32_t)ks * 128u);
+    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + (uint32_t)ks * 128u, dst + BM * 128 + i * 4096);
   };
-  auto write_lds = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < SA; ++i) *(i32x4*)(buf + lds_wa[i]) = ga[i];
-#pragma unroll
-    for (int i = 0; i < SW; ++i) *(i32x4*)(buf + lds_ww[i]) = gw[i];
-  };
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (ks0 < ks1) {
-    issue_loads(ks0);
-    write_lds(smem);
+  auto dma_wait_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int cur = 0;
-    for (int ks = ks0; ks < ks1; ++ks) {
-      const bool more = ks + 1 < ks1;
-      if (more) issue_loads(ks + 1);
-      const char* buf = smem + cur * BUF;
+  };
+
+  // ---- epilogue of one tile: lane owns output row r = .. + lr, channels 8g + 4*lh + (0..3)
+  f32x16 acc[MB][NB];
+  auto epilogue = [&](const TileC& c) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      int oy_, ox_, img_;
+      const int m = row_to_m(c, wm * WTM + i * 32 + lr, oy_, ox_, img_);
+      if (m >= p.M) continue;
+      if (p.geglu) {
+        if constexpr (NB >= 2) {
+#pragma unroll
+          for (int jp = 0; jp < NB / 2; ++jp)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int na = c.n0 + wn * WTN + (2 * jp) * 32 + 8 * g + 4 * lh;
+              if (na >= p.N) continue;
+              const int no = ((c.n0 + wn * WTN) >> 1) + jp * 32 + 8 * g + 4 * lh;
+              f32x4 ba = *(const f32x4*)(p.bias + na), bg = *(const f32x4*)(p.bias + na + 32);
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = (acc[i][2 * jp][4 * g + e] + ba[e]) * gelu_erf(acc[i][2 * jp + 1][4 * g + e] + bg[e]);
+              *(i32x2*)(Cb + ((size_t)m * p.ldc + no) * sizeof(T)) = pack4<T>(v);
+            }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = c.n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;
+          if (n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          if (p.splitk > 1) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)(p.partial + ((size_t)z * p.M + m) * p.N + n) = o;
+          } else {
+            epilogue4<T>(p, Cb, m, n, v);
+          }
+        }
+    }
+  };
+
+  // ---- software pipeline, continuous across tiles: the loads of the NEXT K-step (or of the next
+  // tile's first K-step) are in flight while the current step's MFMAs run; one barrier per step.
+  TileC ct = tile_coords(tile);
+  setup_loader(ct);
+  issue_loads(ks0, smem);
+  dma_wait_barrier();
+  int cur = 0;
+  while (true) {
+    const int next_tile = tile + nxb;
+    const bool has_next = next_tile < t_end;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](const char* buf) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         typename Tr<T>::v8 fa[MB], fw[NB];
@@ -244,52 +328,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
           for (int j = 0; j < NB; ++j) acc[i][j] = Tr<T>::mfma(fw[j], fa[i], acc[i][j]);
       }
-      if (more) write_lds(smem + (cur ^ 1) * BUF);
-      __syncthreads();
+    };
+    for (int ks = ks0; ks + 1 < ks1; ++ks) {
+      issue_loads(ks + 1, smem + (cur ^ 1) * BUF);   // lands in the other buffer during the MFMAs
+      compute(smem + cur * BUF);
+      dma_wait_barrier();
       cur ^= 1;
     }
-  }
-
-  // ---- epilogue: lane owns output row m = .. + lr, channels 8g + 4*lh + (0..3) of each 32-block
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int m = m0 + wm * WTM + i * 32 + lr;
-    if (m >= p.M) continue;
-    if (p.geglu) {
-      if constexpr (NB >= 2) {
-#pragma unroll
-        for (int jp = 0; jp < NB / 2; ++jp)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int na = n0 + wn * WTN + (2 * jp) * 32 + 8 * g + 4 * lh;
-            if (na >= p.N) continue;
-            const int no = ((n0 + wn * WTN) >> 1) + jp * 32 + 8 * g + 4 * lh;
-            f32x4 ba = *(const f32x4*)(p.bias + na), bg = *(const f32x4*)(p.bias + na + 32);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = (acc[i][2 * jp][4 * g + e] + ba[e]) * gelu_erf(acc[i][2 * jp + 1][4 * g + e] + bg[e]);
-            *(i32x2*)(Cb + ((size_t)m * p.ldc + no) * sizeof(T)) = pack4<T>(v);
-          }
-      }
-      continue;
+    // last K-step of the tile (peeled): prefetch the next tile's first step, then the epilogue's
+    // stores go out while that DMA is still landing
+    if (has_next) {
+      setup_loader(tile_coords(next_tile));
+      issue_loads(ks0, smem + (cur ^ 1) * BUF);
     }
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        if (p.splitk > 1) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)(p.partial + ((size_t)z * p.M + m) * p.N + n) = o;
-        } else {
-          epilogue4<T>(p, Cb, m, n, v);
-        }
-      }
+    compute(smem + cur * BUF);
+    epilogue(ct);
+    dma_wait_barrier();
+    cur ^= 1;
+    if (!has_next) break;
+    tile = next_tile;
+    ct = tile_coords(tile);
   }
 }
 
@@ -315,8 +373,25 @@ static int launch_tile(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.ntm = (p.M + BM - 1) / BM;
   q.ntn = (p.N + BN - 1) / BN;
-  dim3 grid(q.ntm * q.ntn, p.batch > 1 ? p.batch : (p.splitk > 1 ? p.splitk : 1));
+  q.tw = 0; q.tw_log2 = 0; q.tpr = 0; q.tpi = 0;
+  if (p.taps == 9) {
+    const int tw = 16, th = BM / tw;
+    if (p.Wo % tw == 0 && p.Ho % th == 0) {
+      q.tw = tw; q.tw_log2 = 4;
+      q.tpr = p.Wo / tw;
+      q.tpi = q.tpr * (p.Ho / th);
+    }
+  }
+  // persistent workgroups: enough to fill 256 CUs at the tile's LDS-limited residency, multiple of 8
   const size_t lds = 2 * (BM + BN) * 128;
+  const int per_cu = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
+  const int zdim = p.batch > 1 ? p.batch : (p.splitk > 1 ? p.splitk : 1);
+  int nwg = q.ntm * q.ntn;
+  int cap = 256 * per_cu / (zdim < 4 ? zdim : 4);
+  if (cap < 256) cap = 256;
+  if (nwg > cap) nwg = cap;
+  nwg = (nwg + 7) & ~7;
+  dim3 grid(nwg, zdim);
   if (p.taps == 1) {
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false>), grid, dim3(256), lds, st, q);
   } else {

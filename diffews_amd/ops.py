@@ -66,7 +66,8 @@ def _gemm_call(a):
         e0.record()
         _gemm_launch(lib, a)
         e1.record()
-        gemm_hook(buf.value.decode() + ("+splitk" if a.splitk > 1 else ""), 2.0 * a.M * a.N * a.K * max(1, a.batch), e0, e1)
+        gemm_hook(buf.value.decode() + ("+splitk" if a.splitk > 1 else ""), 2.0 * a.M * a.N * a.K * max(1, a.batch), e0, e1,
+                  (a.M, a.N, a.K, a.taps, a.stride, a.ups, a.splitk, max(1, a.batch)))
         return
     _gemm_launch(lib, a)
 
