@@ -15,6 +15,7 @@
 // M tiles and N padding read as zero with no divergent branches.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace dfw {
 
@@ -28,6 +29,7 @@ struct GemmP {
   int act, geglu, out_mode, splitk, batch;
   long long strideA, strideW, strideC;
   int nk, cpt, ntn, ntm;
+  int plan_bm, plan_bn;
   int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
 };
 
@@ -408,22 +410,54 @@ static int launch_tile(const GemmP& p, hipStream_t st) {
   return 0;
 }
 
-// Tile choice: the 128x128 tile has the best MFMA:load ratio; fall back to narrower tiles when
-// it would leave most of the 256 CUs idle or waste half a tile on N padding.
-static void pick_tile(const GemmP& p, int& bm, int& bn) {
-  const long long z = p.batch > 1 ? p.batch : p.splitk;
-  const bool n128 = (p.N % 128) == 0 || p.N >= 1024;
-  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * z;
-  const long long t64 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * z;
-  if (p.geglu || (p.M >= 128 && n128 && t128 >= 192)) { bm = 128; bn = 128; }
-  else if (p.M >= 128 && t64 >= 192) { bm = 128; bn = 64; }
-  else { bm = 64; bn = 64; }
+// Tile + split-K plan from a small cost model fitted on MI355X measurements (scratch/bench_small.py):
+//   R   = K-steps per microsecond a CU sustains with its resident workgroups of that tile,
+//   L   = K-step latency of a workgroup that is alone on its CU (the critical path when the grid
+//         is smaller than the chip),
+//   split-K adds the fp32 slab round trip and a second launch.
+// The weight-bound 8x8 / 16x16 UNet levels pick 128-wide tiles with split-K 4..8, the token GEMMs of
+// the 64x64 level pick narrow tiles, the big VAE convs 128x128 without split.
+struct TileCost { int bm, bn; float R, L; };
+static const TileCost kTiles[3] = {{128, 128, 1.67f, 0.70f}, {128, 64, 2.8f, 0.50f}, {64, 64, 3.7f, 0.40f}};
+
+static void plan_gemm(GemmP& p, int& bm, int& bn) {
+  static const char* force = getenv("DFW_GEMM_TILE");  // experiments only: "128x128", "128x64", "64x64"
+  const bool fixed_sk = p.splitk >= 1;
+  if (p.geglu) { bm = 128; bn = 128; p.splitk = 1; return; }
+  const bool can_split = p.batch <= 1 && (p.N % 4) == 0;
+  float best = 1e30f;
+  int best_t = 0, best_sk = 1;
+  for (int t = 0; t < 3; ++t) {
+    const TileCost& tc = kTiles[t];
+    if (force) {
+      int fm, fn;
+      if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm != tc.bm || fn != tc.bn)) continue;
+    }
+    const double tiles = (double)((p.M + tc.bm - 1) / tc.bm) * ((p.N + tc.bn - 1) / tc.bn) * (p.batch > 1 ? p.batch : 1);
+    for (int sk = 1; sk <= 16; sk *= 2) {
+      if (!fixed_sk && sk > 1 && (!can_split || p.nk / sk < 8)) continue;
+      const int use_sk = fixed_sk ? p.splitk : sk;
+      const double blocks = tiles * use_sk, ksteps = (double)p.nk / use_sk;
+      const double busy = blocks < 256.0 ? blocks : 256.0;
+      double t_us = blocks * ksteps / busy / tc.R;
+      const double crit = ksteps * tc.L * (blocks > 256.0 * 2 ? 1.0 : 1.0);
+      if (crit > t_us) t_us = crit;
+      t_us += 3.0;
+      if (use_sk > 1) t_us += 3.0 + 2.0 * use_sk * (double)p.M * p.N * 4.0 / 3.0e6;
+      if (t_us < best) { best = (float)t_us; best_t = t; best_sk = use_sk; }
+      if (fixed_sk) break;
+    }
+  }
+  bm = kTiles[best_t].bm;
+  bn = kTiles[best_t].bn;
+  p.splitk = best_sk;
+  if (p.splitk > p.nk) p.splitk = p.nk;
+  if (p.splitk < 1) p.splitk = 1;
 }
 
 template <typename T>
 static int launch_gemm(const GemmP& p, hipStream_t st) {
-  int bm, bn;
-  pick_tile(p, bm, bn);
+  int bm = p.plan_bm, bn = p.plan_bn;
   if (bm == 128 && bn == 128) return launch_tile<T, 128, 128>(p, st);
   if (bm == 128) return launch_tile<T, 128, 64>(p, st);
   return launch_tile<T, 64, 64>(p, st);
@@ -448,7 +482,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   if (a->a_elems * esz >= (1ll << 31) || a->w_elems * esz >= (1ll << 31)) return DFW_ERANGE;
   if (a->w_elems < (int64_t)a->N * a->K) return DFW_EINVAL;
   const int batch = a->batch > 1 ? a->batch : 1;
-  const int splitk = a->splitk > 1 ? a->splitk : 1;
+  const int splitk = a->splitk >= 1 ? a->splitk : 0;  // 0 = let plan_gemm choose
   if (batch > 1 && splitk > 1) return DFW_ESHAPE;
   if (a->geglu && (splitk > 1 || batch > 1 || a->N % 128 != 0 || !a->bias || a->out_mode != DFW_OUT_T ||
                    a->residual || a->rowbias))
@@ -478,6 +512,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
   if (p.splitk > p.nk) p.splitk = p.nk;
+  plan_gemm(p, p.plan_bm, p.plan_bn);
   return 0;
 }
 
@@ -487,16 +522,16 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   int rc = fill_params(a, p, esz);
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
-  int bm, bn;
-  pick_tile(p, bm, bn);
-  snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", bm, bn,
-           a->taps == 9 ? "conv" : "lin");
+  snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>%s", a->dtype == DFW_BF16 ? "bf16" : "f16", p.plan_bm, p.plan_bn,
+           a->taps == 9 ? "conv" : "lin", p.splitk > 1 ? "+splitk" : "");
   return 0;
 }
 
 extern "C" size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a) {
-  if (!a || a->splitk <= 1) return 0;
-  return (size_t)a->splitk * (size_t)a->M * (size_t)a->N * sizeof(float);
+  GemmP p;
+  int esz;
+  if (fill_params(a, p, esz) || p.splitk <= 1) return 0;
+  return (size_t)p.splitk * (size_t)p.M * (size_t)p.N * sizeof(float);
 }
 
 extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {

@@ -44,14 +44,6 @@ def _rowbias(a, rb):
     a.rowbias, a.ld_rowbias = rb.data_ptr(), rb.stride(0)
 
 
-def auto_splitk(M, N, K):
-    nk = K // 64
-    tiles = math.ceil(M / 64) * math.ceil(N / 64)
-    if tiles >= 256 or nk < 8:
-        return 1
-    return max(1, min(nk // 4, math.ceil(512 / tiles)))
-
-
 # Optional per-launch timing hook (bench.py roofline leg): when set, every GEMM launch is bracketed
 # by events on the launch stream and reported as hook(kernel_name, flops, start_event, end_event).
 gemm_hook = None
@@ -66,19 +58,19 @@ def _gemm_call(a):
         e0.record()
         _gemm_launch(lib, a)
         e1.record()
-        gemm_hook(buf.value.decode() + ("+splitk" if a.splitk > 1 else ""), 2.0 * a.M * a.N * a.K * max(1, a.batch), e0, e1,
+        gemm_hook(buf.value.decode(), 2.0 * a.M * a.N * a.K * max(1, a.batch), e0, e1,
                   (a.M, a.N, a.K, a.taps, a.stride, a.ups, a.splitk, max(1, a.batch)))
         return
     _gemm_launch(lib, a)
 
 
 def _gemm_launch(lib, a):
-    ws = None
-    if a.splitk > 1:
-        nbytes = lib.dfw_gemm_workspace_bytes(C.byref(a))
+    nbytes = lib.dfw_gemm_workspace_bytes(C.byref(a))   # 0 unless the plan uses split-K
+    if nbytes:
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     L.check(lib.dfw_gemm(C.byref(a), _stream()), "dfw_gemm")
+    return
 
 
 def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.ACT_NONE, geglu=False,
@@ -106,7 +98,7 @@ def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.A
     a.rows_per_img = rows_per_img
     a.out_scale, a.act, a.geglu = out_scale, act, int(geglu)
     a.out_mode = L.OUT_F32 if out.dtype == torch.float32 else L.OUT_T
-    a.splitk = (auto_splitk(M, N, K) if not geglu else 1) if splitk is None else splitk
+    a.splitk = 0 if splitk is None else splitk   # 0: the library plans tile + split-K
     a.batch, a.dtype = 1, _dt(x)
     _gemm_call(a)
     return out
@@ -166,7 +158,7 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     a.rows_per_img = Ho * Wo
     a.out_scale = out_scale
     a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else L.OUT_T
-    a.splitk = (auto_splitk(M, cout, 9 * Cin) if cout % 4 == 0 else 1) if splitk is None else splitk
+    a.splitk = 0 if splitk is None else splitk
     a.batch, a.dtype = 1, _dt(x)
     _gemm_call(a)
     return out
