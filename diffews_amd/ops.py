@@ -164,17 +164,19 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     return out
 
 
-def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None):
+def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None):
     """KV-fusion self-attention.  q/k/v: [B, N, heads*64] views (token stride = stride(1));
     k_bank/v_bank: [B*nshot, Nb, heads*64] views written by the support pass."""
     B, N, Cq = q.shape
     assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
-    out = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
+    assert out.shape == (B, N, Cq) and out.stride(2) == 1 and out.stride(1) == Cq
     a = L.FsaArgs()
     a.q, a.k, a.v, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     a.batch, a.heads, a.n_q, a.n_kv = B, heads, N, k.shape[1]
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), Cq
-    a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), N * Cq
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     if nshot:
         assert k_bank.shape[0] == B * nshot and k_bank.stride(2) == 1 and v_bank.stride(2) == 1
         assert k_bank.dtype == q.dtype and v_bank.shape == k_bank.shape

@@ -165,10 +165,9 @@ class MarigoldPipelineRGBLatentNoise:
             ehs = embed.repeat((b, 1, 1))
             ehs_ref = ehs.repeat((n_sup // b, 1, 1))
             tt = t * self.test_timestep
-            self.unet.clear_attn_bank()
-            self.unet(cond_ref, tt, encoder_hidden_states=ehs_ref, is_target=False)
-            z0 = self.unet(z_tag.contiguous(), tt, encoder_hidden_states=ehs, out_scale=-1.0).sample  # z0 = -v
-            self.unet.clear_attn_bank()
+            # support + query passes in layer lock-step (one trunk pass over [support ; query], weights
+            # read once); z0 = -v folded into conv_out.  Same per-image arithmetic as P:715-725.
+            z0 = self.unet.forward_pair(cond_ref, z_tag.contiguous(), tt, ehs_ref, ehs, out_scale=-1.0)
             dec = self.decode_seg(z0)
         seg_u8, counts = ops.seg_postprocess(dec.contiguous(), query_gt, r_threshold)
         return dict(z0=z0, dec=dec, seg_u8=seg_u8, counts=counts)

@@ -92,7 +92,10 @@ class _Transformer:
         self.k_bank = None
         self.v_bank = None
 
-    def __call__(self, x, ehs2d, L_ctx):
+    def __call__(self, x, ehs2d, L_ctx, n_ref=0):
+        """n_ref == 0: reference bank semantics (fill on the first pass after clear, read on the next).
+        n_ref > 0: lock-step pair -- the batch is [n_ref support images ; query images]; the support
+        rows run plain self-attention and are the bank of the query rows within the same call."""
         B, H, W, C = x.shape
         N = H * W
         heads = self.heads
@@ -102,7 +105,15 @@ class _Transformer:
         ln = ops.layernorm(t, *self.ln[0])
         qkv = ops.linear(ln, self.w_qkv).view(B, N, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-        if self.k_bank is None:  # A:251-252 / 260-261: first pass after clear fills the bank
+        if n_ref:
+            bq = B - n_ref
+            if bq <= 0 or n_ref % bq != 0:
+                raise ValueError(f"{n_ref} support images is not a multiple of the {bq} query images")
+            att = torch.empty(B, N, C, dtype=x.dtype, device=x.device)
+            ops.fsa_attention(q[:n_ref], k[:n_ref], v[:n_ref], heads, out=att[:n_ref])
+            ops.fsa_attention(q[n_ref:], k[n_ref:], v[n_ref:], heads, k[:n_ref], v[:n_ref], nshot=n_ref // bq,
+                              out=att[n_ref:])
+        elif self.k_bank is None:  # A:251-252 / 260-261: first pass after clear fills the bank
             self.k_bank, self.v_bank = k, v
             att = ops.fsa_attention(q, k, v, heads)
         else:                    # A:253-258 / 262-267: [own ; bank], ref batch folded into tokens
@@ -272,17 +283,8 @@ class MyUNet2DConditionModel:
         if (h % 8 or w % 8) and False:
             raise ValueError("latent size must be divisible by 8")
         # ---- 1. time (U:991-1015)
-        if torch.is_tensor(timestep) and timestep.device.type == "cpu" and timestep.numel() == 1:
-            timestep = float(timestep)  # host scalar (scheduler.timesteps lives on the host): no H2D copy
-        if not torch.is_tensor(timestep):
-            t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
-        else:
-            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
         c0 = cfg["block_out_channels"][0]
-        temb = ops.timestep_embedding(t, c0, dt, cfg["flip_sin_to_cos"], float(cfg["freq_shift"]))
-        e = ops.linear(temb, self.te_w1, bias=self.te_b1, act=L.ACT_SILU)
-        semb = ops.linear(e, self.te_w2, bias=self.te_b2, act=L.ACT_SILU)  # silu(emb): every consumer applies it
-        tproj = ops.linear(semb, self.tp_w, bias=self.tp_b, out_f32=True)  # [B, sum Cout] fp32
+        tproj = self._time_proj(B, timestep)  # [B, sum Cout] fp32: all 22 time_emb_proj outputs
         # ---- prompt tokens
         ehs = encoder_hidden_states.to(device=dev, dtype=dt)
         if ehs.shape[0] != B:
@@ -298,13 +300,59 @@ class MyUNet2DConditionModel:
             if Cin != cfg["in_channels_ref"]:
                 raise ValueError(f"support pass expects {cfg['in_channels_ref']} channels, got {Cin}")
             x = ops.conv_small(x_in, self.w_in_ref, self.b_in_ref, c0, 9, dt)
+        out = self._trunk(x, tproj, ehs2d, L_ctx, 0, out_scale)
+        if in_dtype in (torch.float16, torch.bfloat16, torch.float64):
+            out = out.to(in_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    def _time_proj(self, B, timestep):
+        cfg, dt, dev = self.config, self.dtype, self.device
+        if torch.is_tensor(timestep) and timestep.device.type == "cpu" and timestep.numel() == 1:
+            timestep = float(timestep)
+        if not torch.is_tensor(timestep):
+            t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
+        else:
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        temb = ops.timestep_embedding(t, cfg["block_out_channels"][0], dt, cfg["flip_sin_to_cos"], float(cfg["freq_shift"]))
+        e = ops.linear(temb, self.te_w1, bias=self.te_b1, act=L.ACT_SILU)
+        semb = ops.linear(e, self.te_w2, bias=self.te_b2, act=L.ACT_SILU)
+        return ops.linear(semb, self.tp_w, bias=self.tp_b, out_f32=True)
+
+    @torch.no_grad()
+    def forward_pair(self, ref_sample, query_sample, timestep, ehs_ref, ehs_query, out_scale=1.0):
+        """Support and query passes in layer lock-step: ONE trunk pass over the batch
+        [support images ; query images] (weights read once, twice the rows per GEMM).  Per image the
+        arithmetic is that of forward(ref, is_target=False) followed by forward(query): every op on
+        the path is per-image (GroupNorm) or per-token, and each query image attends over
+        [own ; its episode's support images] exactly as with the bank (A:251-267).
+        Returns the query pass' output only (the reference discards the support pass' output, P:719)."""
+        cfg, dt, dev = self.config, self.dtype, self.device
+        zr = ref_sample.to(device=dev, dtype=torch.float32).contiguous()
+        zq = query_sample.to(device=dev, dtype=torch.float32).contiguous()
+        n_ref, bq = zr.shape[0], zq.shape[0]
+        if zr.shape[1] != cfg["in_channels_ref"] or zq.shape[1] != cfg["in_channels"]:
+            raise ValueError("forward_pair expects (in_channels_ref, in_channels) channel counts")
+        c0 = cfg["block_out_channels"][0]
+        tproj = self._time_proj(n_ref + bq, timestep)
+        ehs = torch.cat([ehs_ref.to(device=dev, dtype=dt), ehs_query.to(device=dev, dtype=dt)], dim=0)
+        L_ctx = ehs.shape[1]
+        ehs2d = ehs.reshape((n_ref + bq) * L_ctx, ehs.shape[2]).contiguous()
+        x = torch.empty(n_ref + bq, zq.shape[2], zq.shape[3], c0, dtype=dt, device=dev)
+        x[:n_ref] = ops.conv_small(zr, self.w_in_ref, self.b_in_ref, c0, 9, dt)
+        x[n_ref:] = ops.conv_small(zq, self.w_in, self.b_in, c0, 9, dt)
+        out = self._trunk(x, tproj, ehs2d, L_ctx, n_ref, out_scale)
+        return out[n_ref:]
+
+    def _trunk(self, x, tproj, ehs2d, L_ctx, n_ref, out_scale):
         # ---- 3. down (U:1153-1175)
         skips = [x]
         for blk in self.down:
             for j, r in enumerate(blk["res"]):
                 x = r(x, tproj)
                 if blk["attn"] is not None:
-                    x = blk["attn"][j](x, ehs2d, L_ctx)
+                    x = blk["attn"][j](x, ehs2d, L_ctx, n_ref)
                 skips.append(x)
             if blk["down"] is not None:
                 d = blk["down"]
@@ -312,7 +360,7 @@ class MyUNet2DConditionModel:
                 skips.append(x)
         # ---- 4. mid (U:1189-1198)
         x = self.mid["res"][0](x, tproj)
-        x = self.mid["attn"](x, ehs2d, L_ctx)
+        x = self.mid["attn"](x, ehs2d, L_ctx, n_ref)
         x = self.mid["res"][1](x, tproj)
         # ---- 5. up (U:1214-1243)
         for blk in self.up:
@@ -320,19 +368,14 @@ class MyUNet2DConditionModel:
                 x = ops.concat_channels(x, skips.pop())
                 x = r(x, tproj)
                 if blk["attn"] is not None:
-                    x = blk["attn"][j](x, ehs2d, L_ctx)
+                    x = blk["attn"][j](x, ehs2d, L_ctx, n_ref)
             if blk["up"] is not None:
                 u = blk["up"]
                 x = ops.conv3x3(x, u.w, u.cout, bias=u.b, ups=True)
         # ---- 6. out (U:1246-1249); out_scale lets the pipeline fold z0 = -v into the epilogue
         x = ops.groupnorm(x, *self.gn_out, self.groups, self.eps, silu=True)
         co = self.conv_out
-        out = ops.conv3x3(x, co.w, co.cout, bias=co.b, out_nchw_f32=True, out_scale=out_scale)
-        if in_dtype in (torch.float16, torch.bfloat16, torch.float64):
-            out = out.to(in_dtype)
-        if not return_dict:
-            return (out,)
-        return UNet2DConditionOutput(sample=out)
+        return ops.conv3x3(x, co.w, co.cout, bias=co.b, out_nchw_f32=True, out_scale=out_scale)
 
 
 CustomUNet2DConditionModel = MyUNet2DConditionModel  # name used by evaluation_util/main_oss.py:27

@@ -93,6 +93,31 @@ def test_unet_two_pass_bank(models):
         assert rel(out_q, ref_q) < TOL_Z0[dt], (b, s, hw)
 
 
+def test_lockstep_pair_equals_two_passes(models):
+    """forward_pair (one trunk pass over [support ; query]) == forward(ref) then forward(query)
+    with the bank: same per-image arithmetic; only GroupNorm partial-sum chunking and the GEMM tile /
+    split-K plan depend on the batch size, so equality holds at rounding-noise level."""
+    unet, te, dt = models["unet"], models["te"], models["dt"]
+    g = torch.Generator().manual_seed(5)
+    for b, s in [(1, 1), (2, 2)]:
+        zr = (torch.randn(b * s, 8, 16, 16, generator=g) * 0.5).cuda()
+        zq = (torch.randn(b, 4, 16, 16, generator=g) * 0.5).cuda()
+        ehs, ehs_r = te.repeat(b, 1, 1).cuda(), te.repeat(b * s, 1, 1).cuda()
+        unet.clear_attn_bank()
+        unet(zr, 1, ehs_r, is_target=False)
+        two = unet(zq, 1, ehs).sample
+        unet.clear_attn_bank()
+        pair = unet.forward_pair(zr, zq, 1, ehs_r, ehs)
+        assert pair.shape == two.shape
+        assert rel(pair, two) < TOL_Z0[dt], (b, s)
+        with torch.no_grad():
+            models["ou"].clear_attn_bank()
+            models["ou"](zr.cpu(), 1, ehs_r.cpu(), is_target=False)
+            ref = models["ou"](zq.cpu(), 1, ehs.cpu())
+            models["ou"].clear_attn_bank()
+        assert rel(pair, ref) < TOL_Z0[dt], (b, s)
+
+
 def test_bank_semantics(models):
     """(i) a pass right after clear_attn_bank is plain self-attention whatever ran before;
     (ii) forgetting to clear turns the next pass into a read pass (reference behaviour, A:251-258)."""
