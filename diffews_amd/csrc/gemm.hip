@@ -13,86 +13,11 @@
 // k+1 are issued before the MFMAs of step k and written to the other buffer after them, one
 // barrier per K-step.  All global loads are bounds-checked buffer loads, so conv halos, ragged
 // M tiles and N padding read as zero with no divergent branches.
-#include "common.h"
+#include "gemm_common.h"
 #include <stdio.h>
 #include <stdlib.h>
 
 namespace dfw {
-
-struct GemmP {
-  const char* A; const char* W; char* C;
-  const float* bias; const float* rowbias; const char* residual; float* partial;
-  uint32_t a_bytes, w_bytes;
-  int M, N, K, lda, ldc, ldr, ldrb;
-  int taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups, rows_per_img;
-  float out_scale;
-  int act, geglu, out_mode, splitk, batch;
-  long long strideA, strideW, strideC;
-  int nk, cpt, ntn, ntm;
-  int plan_bm, plan_bn;
-  int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
-};
-
-// Epilogue for 4 consecutive output channels n..n+3 of output row m (raw fp32 accumulators in v).
-template <typename T>
-__device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n, float* v) {
-  const bool vec = (p.N & 3) == 0;
-  if (vec) {
-    if (p.bias) {
-      f32x4 b = *(const f32x4*)(p.bias + n);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += b[i];
-    }
-    if (p.rowbias) {
-      f32x4 b = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_img) * p.ldrb + n);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += b[i];
-    }
-    if (p.residual) {
-      float r[4];
-      unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += r[i];
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (n + i < p.N) {
-        if (p.bias) v[i] += p.bias[n + i];
-        if (p.rowbias) v[i] += p.rowbias[(size_t)(m / p.rows_per_img) * p.ldrb + n + i];
-        if (p.residual) v[i] += to_f(((const T*)p.residual)[(size_t)m * p.ldr + n + i]);
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[i] *= p.out_scale;
-    if (p.act == DFW_ACT_SILU) v[i] = silu_f(v[i]);
-  }
-  if (p.out_mode == DFW_OUT_T && vec) {
-    *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
-  } else if (p.out_mode == DFW_OUT_F32 && vec) {
-    f32x4 o = {v[0], v[1], v[2], v[3]};
-    *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = o;
-  } else if (p.out_mode == DFW_OUT_NCHW_F32) {
-    const int img = m / p.rows_per_img, pix = m - img * p.rows_per_img;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (n + i < p.N) ((float*)Cb)[((size_t)img * p.N + n + i) * p.rows_per_img + pix] = v[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (n + i < p.N) {
-        if (p.out_mode == DFW_OUT_T) ((T*)Cb)[(size_t)m * p.ldc + n + i] = from_f<T>(v[i]);
-        else ((float*)Cb)[(size_t)m * p.ldc + n + i] = v[i];
-      }
-  }
-}
-
-// Tile coordinates of one output tile (uniform per workgroup).
-struct TileC {
-  int m0, n0;                 // first output row (linear tiles) / first output channel
-  int img, oy0, ox0;          // 2-D conv tiles: image and top-left output pixel
-};
 
 template <typename T, int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
@@ -511,6 +436,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.splitk = splitk; p.batch = batch;
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
+  p.dtype_bf16 = a->dtype == DFW_BF16;
   if (p.splitk > p.nk) p.splitk = p.nk;
   plan_gemm(p, p.plan_bm, p.plan_bn);
   return 0;
@@ -522,6 +448,12 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   int rc = fill_params(a, p, esz);
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
+  int big_bn = 0;
+  if (gemm_big_eligible(p, big_bn)) {
+    snprintf(buf, n, "gemm_big_kernel<%s,256,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bn,
+             a->taps == 9 ? "conv" : "lin");
+    return 0;
+  }
   snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>%s", a->dtype == DFW_BF16 ? "bf16" : "f16", p.plan_bm, p.plan_bn,
            a->taps == 9 ? "conv" : "lin", p.splitk > 1 ? "+splitk" : "");
   return 0;
@@ -543,5 +475,7 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
     if (!a->workspace || a->workspace_bytes < (size_t)p.splitk * p.M * p.N * sizeof(float)) return DFW_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  int big_bn = 0;
+  if (gemm_big_eligible(p, big_bn)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
 }

@@ -1,0 +1,86 @@
+// Shared between gemm.hip (128-wide tiles) and gemm_big.hip (256-row tiles): kernel parameters,
+// the epilogue for 4 consecutive output channels, tile coordinates.
+#pragma once
+#include "common.h"
+
+namespace dfw {
+
+struct GemmP {
+  const char* A; const char* W; char* C;
+  const float* bias; const float* rowbias; const char* residual; float* partial;
+  uint32_t a_bytes, w_bytes;
+  int M, N, K, lda, ldc, ldr, ldrb;
+  int taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups, rows_per_img;
+  float out_scale;
+  int act, geglu, out_mode, splitk, batch;
+  long long strideA, strideW, strideC;
+  int nk, cpt, ntn, ntm;
+  int plan_bm, plan_bn, dtype_bf16;
+  int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
+};
+
+// Epilogue for 4 consecutive output channels n..n+3 of output row m (raw fp32 accumulators in v).
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n, float* v) {
+  const bool vec = (p.N & 3) == 0;
+  if (vec) {
+    if (p.bias) {
+      f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += b[i];
+    }
+    if (p.rowbias) {
+      f32x4 b = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_img) * p.ldrb + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += b[i];
+    }
+    if (p.residual) {
+      float r[4];
+      unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < p.N) {
+        if (p.bias) v[i] += p.bias[n + i];
+        if (p.rowbias) v[i] += p.rowbias[(size_t)(m / p.rows_per_img) * p.ldrb + n + i];
+        if (p.residual) v[i] += to_f(((const T*)p.residual)[(size_t)m * p.ldr + n + i]);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] *= p.out_scale;
+    if (p.act == DFW_ACT_SILU) v[i] = silu_f(v[i]);
+  }
+  if (p.out_mode == DFW_OUT_T && vec) {
+    *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
+  } else if (p.out_mode == DFW_OUT_F32 && vec) {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = o;
+  } else if (p.out_mode == DFW_OUT_NCHW_F32) {
+    const int img = m / p.rows_per_img, pix = m - img * p.rows_per_img;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < p.N) ((float*)Cb)[((size_t)img * p.N + n + i) * p.rows_per_img + pix] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < p.N) {
+        if (p.out_mode == DFW_OUT_T) ((T*)Cb)[(size_t)m * p.ldc + n + i] = from_f<T>(v[i]);
+        else ((float*)Cb)[(size_t)m * p.ldc + n + i] = v[i];
+      }
+  }
+}
+
+// Tile coordinates of one output tile (uniform per workgroup).
+struct TileC {
+  int m0, n0;                 // first output row (linear tiles) / first output channel
+  int img, oy0, ox0;          // 2-D conv tiles: image and top-left output pixel
+};
+
+int launch_gemm_big(const GemmP& p, hipStream_t st);  // gemm_big.hip
+bool gemm_big_eligible(const GemmP& p, int& bn);
+
+}  // namespace dfw

@@ -108,6 +108,41 @@ def test_conv3x3(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ups", [(3, 128, 128, 64, 256, False), (3, 128, 128, 64, 128, False),
+                                               (1, 112, 240, 128, 256, False), (2, 80, 80, 64, 128, True)])
+def test_conv3x3_big_tiles(ops, dtype, B, H, W, Cin, Cout, ups):
+    """Shapes large enough for the 256-row LDS-DMA ring kernel (gemm_big.hip), incl. residual,
+    per-image bias and the fused nearest-2x upsample."""
+    from diffews_amd.packing import pack_conv3x3
+    x = rnd((B, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)
+    bias, rb = torch.randn(Cout), torch.randn(B, Cout)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), bias, padding=1) + rb[:, :, None, None]
+    res = rnd(tuple(ref.shape), dtype, 3)
+    ref = (ref + res.float()) * 0.5
+    y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv3x3(w).cuda(), Cout, bias=bias.cuda(),
+                    ups=ups, rowbias=rb.cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda(), out_scale=0.5)
+    assert rel(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_big_tiles(ops, dtype):
+    from diffews_amd.packing import pack_geglu
+    for M, N, K in [(49152, 256, 128), (24576, 384, 320), (50000, 128, 64 * 3)]:
+        x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+        bias, res = torch.randn(N), rnd((M, N), dtype, 3)
+        ref = x.float() @ w.float().t() + bias + res.float()
+        assert rel(ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda()), ref) < TOL[dtype], (M, N, K)
+    M, C = 12288, 128
+    x = rnd((M, C), dtype, 1)
+    w, b = rnd((8 * C, C), dtype, 2, C ** -0.5), torch.randn(8 * C) * 0.1
+    a, g = (x.float() @ w.float().t() + b).chunk(2, dim=-1)
+    wp, bp = pack_geglu(w, b)
+    assert rel(ops.linear(x.cuda(), wp.cuda(), bias=bp.cuda(), geglu=True), a * F.gelu(g)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Cout", [3, 4, 8])
 def test_conv3x3_small_cout_nchw(ops, dtype, Cout):
     from diffews_amd.packing import pack_conv3x3
