@@ -448,9 +448,9 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   int rc = fill_params(a, p, esz);
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
-  int big_bn = 0;
-  if (gemm_big_eligible(p, big_bn)) {
-    snprintf(buf, n, "gemm_big_kernel<%s,256,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bn,
+  int big_bm = 0, big_bn = 0, big_bk = 0;
+  if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
+    snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn, big_bk,
              a->taps == 9 ? "conv" : "lin");
     return 0;
   }
@@ -475,7 +475,7 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
     if (!a->workspace || a->workspace_bytes < (size_t)p.splitk * p.M * p.N * sizeof(float)) return DFW_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  int big_bn = 0;
-  if (gemm_big_eligible(p, big_bn)) return launch_gemm_big(p, st);
+  int big_bm = 0, big_bn = 0, big_bk = 0;
+  if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
 }

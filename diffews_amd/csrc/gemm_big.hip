@@ -17,6 +17,8 @@
 // Wave tile: (256/WGM) x 64, v_mfma_f32_32x32x16, D[n][m] orientation (lane owns 4 contiguous
 // output channels), same epilogue as gemm.hip.
 #include "gemm_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace dfw {
 
@@ -44,14 +46,16 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-template <typename T, int BN, bool CONV>
-__global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
-  constexpr int BM = 256, S = 4;
+template <typename T, int BM, int BN, int BK, int S, int OCC, bool CONV>
+__global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
+  // S ring stages (S-1 in flight); OCC workgroups per CU (2 * OCC waves per SIMD)
+  constexpr int CH = BK / 8, RB = BK * 2;       // 16-byte chunks per row, bytes per row
+  constexpr int RPI = 1024 / RB;                // tile rows per DMA wave-instruction
   constexpr int WGN = BN / 64, WGM = 8 / WGN;   // wave grid: 2x4 (BN=256) or 4x2 (BN=128)
   constexpr int WTM = BM / WGM;                 // 128 or 64
   constexpr int MB = WTM / 32, NB = 2;
-  constexpr int STAGE = (BM + BN) * 64;         // bytes
-  constexpr int SA = 2, SW = BN / 128;          // DMA wave-instructions per stage per wave
+  constexpr int STAGE = (BM + BN) * RB;         // bytes
+  constexpr int SA = BM / RPI / 8, SW = BN / RPI / 8;   // DMA wave-instructions per stage per wave
   constexpr int DPS = SA + SW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
   const int tile0 = xcd * Q + (blockIdx.x >> 3);
   if (tile0 >= t_end) return;
   const int my_tiles = (t_end - tile0 + nxb - 1) / nxb;
-  const int nks = p.K >> 5;            // K-steps of 32
-  const int cpt = p.Cin >> 5;          // K-steps per tap
+  const int nks = p.K / BK;            // K-steps
+  const int cpt = p.Cin / BK;          // K-steps per tap
 
   const int z = blockIdx.y;
   const char* Ab = p.A;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
     if constexpr (CONV) {
       c.img = tm / p.tpi;
       const int t2 = tm - c.img * p.tpi, tyi = t2 / p.tpr, txi = t2 - tyi * p.tpr;
-      c.oy0 = tyi << 4;
+      c.oy0 = tyi * (BM / 16);
       c.ox0 = txi << 4;
     }
     return c;
@@ -110,10 +114,14 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
     }
   };
 
-  // ---- loader: wave-instruction i of a wave covers tile rows (i*8 + wave)*16 .. +16,
-  // lane -> row + (lane>>2), LDS slot lane&3, source chunk = slot ^ ((row>>2)&3) = slot ^ ((lane>>4)&3)
-  const int lrow = lane >> 2;
-  const int kc = (lane & 3) ^ ((lane >> 4) & 3);
+  // ---- loader: wave-instruction i of a wave covers tile rows (i*8 + wave)*RPI .. +RPI (1 KiB of
+  // LDS, written linearly: lane -> row + lane/CH, 16-byte slot lane%CH).  The bank swizzle lives
+  // on the SOURCE side: slot j of a row holds global chunk j ^ swz(row), with
+  //   BK = 32 (64-B rows):  swz = (row>>2)&3      BK = 64 (128-B rows, full cache lines): swz = (row>>1)&7
+  // which depends only on the lane (and the wave's parity), not on i.
+  const int lrow = lane / CH;
+  const int kc = BK == 32 ? ((lane & 3) ^ ((lrow >> 2) & 3))
+                          : ((lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7));
   uint32_t a_off[SA];
   int a_iy0[SA], a_ix0[SA];
   uint32_t a_pix[SA];
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < SA; ++i) {
       int oy = 0, ox = 0, img = 0;
-      const int m = row_to_m(c, (i * 8 + wave) * 16 + lrow, oy, ox, img);
+      const int m = row_to_m(c, (i * 8 + wave) * RPI + lrow, oy, ox, img);
       if constexpr (!CONV) {
         a_off[i] = m < p.M ? (uint32_t)(((size_t)m * p.lda + kc * 8) * sizeof(T)) : kOOB;
       } else {
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
     }
 #pragma unroll
     for (int i = 0; i < SW; ++i) {
-      const int n = c.n0 + (i * 8 + wave) * 16 + lrow;
+      const int n = c.n0 + (i * 8 + wave) * RPI + lrow;
       w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
     }
     tap = 0;
@@ -152,10 +160,10 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
     const uint32_t dst = lds0 + (uint32_t)slot * STAGE + (uint32_t)wave * 1024u;
     if constexpr (!CONV) {
 #pragma unroll
-      for (int i = 0; i < SA; ++i) dma16(ra, a_off[i] + (uint32_t)ks * 64u, dst + i * 8192);
+      for (int i = 0; i < SA; ++i) dma16(ra, a_off[i] + (uint32_t)ks * RB, dst + i * 8192);
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
-      const uint32_t coff = (uint32_t)(cc * 32 + kc * 8);
+      const uint32_t coff = (uint32_t)(cc * BK + kc * 8);
 #pragma unroll
       for (int i = 0; i < SA; ++i) {
         int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
@@ -168,15 +176,15 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
       if (++cc == cpt) { cc = 0; ++tap; }
     }
 #pragma unroll
-    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + (uint32_t)ks * 64u, dst + BM * 64 + i * 8192);
+    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + (uint32_t)ks * RB, dst + BM * RB + i * 8192);
   };
   // ---- fragment read addresses within a stage (k-substep s: ^ (s<<5))
   uint32_t lds_ra[MB], lds_rw[NB];
-  const int sw4 = (lr >> 2) & 3;
+  const int sw4 = BK == 32 ? ((lr >> 2) & 3) : ((lr >> 1) & 7);
 #pragma unroll
-  for (int i = 0; i < MB; ++i) lds_ra[i] = (uint32_t)(wm * WTM + i * 32 + lr) * 64u + (uint32_t)((lh ^ sw4) << 4);
+  for (int i = 0; i < MB; ++i) lds_ra[i] = (uint32_t)(wm * WTM + i * 32 + lr) * RB + (uint32_t)((lh ^ sw4) << 4);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) lds_rw[j] = (uint32_t)(BM + wn * 64 + j * 32 + lr) * 64u + (uint32_t)((lh ^ sw4) << 4);
+  for (int j = 0; j < NB; ++j) lds_rw[j] = (uint32_t)(BM + wn * 64 + j * 32 + lr) * RB + (uint32_t)((lh ^ sw4) << 4);
 
   f32x16 acc[MB][NB];
   auto zero_acc = [&]() {
@@ -187,12 +195,18 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
-  auto epilogue = [&](const TileC& c) {
+  // Epilogue.  Non-GEGLU tiles are stored through a 4 KiB per-wave LDS staging area (the ring slot
+  // that was read last and is free until the next barrier): the accumulator layout gives each lane
+  // 4 channels of one row (8-byte pieces of 32 different rows per store instruction); after the
+  // round trip a lane holds 16 contiguous bytes and a store instruction covers 8 rows x 128 B of
+  // whole cache lines -- half the store instructions, no partial-line writes.
+  constexpr bool kStage = STAGE >= 8 * 4096;
+  auto epilogue = [&](const TileC& c, char* stg) {
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       int oy_ = 0, ox_ = 0, img_ = 0;
       const int m = row_to_m(c, wm * WTM + i * 32 + lr, oy_, ox_, img_);
-      if (m >= p.M) continue;
+      if (m >= p.M && (!kStage || p.geglu)) continue;
       if constexpr (!CONV) img_ = p.rowbias ? m / p.rows_per_img : 0;
       if (p.geglu) {
 #pragma unroll
@@ -213,7 +227,6 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = c.n0 + wn * 64 + j * 32 + 8 * g + 4 * lh;
-          if (n >= p.N) continue;
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
@@ -222,12 +235,12 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += b[e];
           }
-          if (p.rowbias) {
+          if (p.rowbias && m < p.M) {
             const f32x4 b = *(const f32x4*)(p.rowbias + (size_t)img_ * p.ldrb + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += b[e];
           }
-          if (p.residual) {
+          if (p.residual && m < p.M) {
             float r[4];
             unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
 #pragma unroll
@@ -235,15 +248,33 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-          *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
+          if constexpr (kStage) {
+            const int c16 = j * 4 + g;  // 16-byte chunk of the wave tile's 128-byte row
+            *(i32x2*)(stg + lr * 128 + ((c16 ^ (lr & 7)) << 4) + lh * 8) = pack4<T>(v);
+          } else {
+            *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
+          }
         }
+      if constexpr (kStage) {
+        // same wave wrote and reads this region: program order + the compiler's lgkmcnt wait suffice
+        const int c16 = lane & 7;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = (lane >> 3) + 8 * t;
+          int oy2 = 0, ox2 = 0, img2 = 0;
+          const int m2 = row_to_m(c, wm * WTM + i * 32 + r, oy2, ox2, img2);
+          const i32x4 val = *(const i32x4*)(stg + r * 128 + ((c16 ^ (r & 7)) << 4));
+          if (m2 < p.M)
+            *(i32x4*)(Cb + ((size_t)m2 * p.ldc + c.n0 + wn * 64 + c16 * 8) * sizeof(T)) = val;
+        }
+      }
     }
   };
 
   auto compute = [&](int slot) {
     const char* buf = smem + slot * STAGE;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < BK / 16; ++s) {
       typename Tr<T>::v8 fa[MB], fw[NB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) fa[i] = as_v8<T>(*(const i32x4*)(buf + (lds_ra[i] ^ (s << 5))));
@@ -265,43 +296,50 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const GemmP p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  auto nxt = [](int slot) { return slot + 1 == S ? 0 : slot + 1; };
 
-  // ---- pipeline: ring slot of (tile-local) K-step k is (base + k) & 3; three stages in flight.
-  // nks >= 4 (host-checked).  The hot loop is branch-free; the last three steps of a tile stage the
-  // first three steps of the next tile, so the ring never drains between tiles.
+  // ---- pipeline: S-1 stages in flight; rs = slot read this step, ws = slot written this step.
+  // nks >= S (host-checked).  The hot loop is branch-free; the last S-1 steps of a tile stage the
+  // first S-1 steps of the next tile, so the ring never drains between tiles.
   TileC ct = tile_coords(tile0);
   setup_loader(ct);
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
-  int base = 0;  // ring slot of this tile's step 0
+  int rs = 0, ws = 0;
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i) { issue(i, ws); ws = nxt(ws); }
   for (int ti = 0; ti < my_tiles; ++ti) {
     const bool has_next = ti + 1 < my_tiles;
     zero_acc();
-    for (int k = 0; k < nks - 3; ++k) {
-      wait_vm<2 * DPS>();
+    for (int k = 0; k < nks - (S - 1); ++k) {
+      wait_vm<(S - 2) * DPS>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue(k + 3, (base + k + 3) & 3);
-      compute((base + k) & 3);
+      issue(k + S - 1, ws);
+      ws = nxt(ws);
+      compute(rs);
+      rs = nxt(rs);
     }
     if (has_next) setup_loader(tile_coords(tile0 + (ti + 1) * nxb));
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int k = nks - 3 + j;
-      retire_and_sync(has_next ? 2 : 2 - j);
-      if (has_next) issue(j, (base + k + 3) & 3);
-      compute((base + k) & 3);
+    for (int j = 0; j < S - 1; ++j) {
+      retire_and_sync(has_next ? S - 2 : S - 2 - j);
+      if (has_next) { issue(j, ws); ws = nxt(ws); }
+      compute(rs);
+      rs = nxt(rs);
     }
-    epilogue(ct);
-    base = (base + nks) & 3;
+    char* stg = nullptr;
+    if constexpr (kStage) {
+      __builtin_amdgcn_s_barrier();   // every wave is done reading the last stage: its slot is free
+      asm volatile("" ::: "memory");
+      stg = smem + (rs == 0 ? S - 1 : rs - 1) * STAGE + wave * 4096;
+    }
+    epilogue(ct, stg);
     if (has_next) ct = tile_coords(tile0 + (ti + 1) * nxb);
+    else ws = rs;
   }
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN, int BK, int S, int OCC>
 static int launch_big(const GemmP& p, hipStream_t st) {
-  constexpr int BM = 256;
   GemmP q = p;
   q.ntm = (p.M + BM - 1) / BM;
   q.ntn = (p.N + BN - 1) / BN;
@@ -309,21 +347,21 @@ static int launch_big(const GemmP& p, hipStream_t st) {
   if (p.taps == 9) {
     q.tw = 16; q.tw_log2 = 4;
     q.tpr = p.Wo / 16;
-    q.tpi = q.tpr * (p.Ho / 16);
+    q.tpi = q.tpr * (p.Ho / (BM / 16));
   }
-  const size_t lds = 4 * (BM + BN) * 64;
+  const size_t lds = (size_t)S * (BM + BN) * BK * 2;
   const int zdim = p.batch > 1 ? p.batch : 1;
   int nwg = q.ntm * q.ntn;
-  if (nwg > 256) nwg = 256;
+  if (nwg > 256 * OCC) nwg = 256 * OCC;
   nwg = (nwg + 7) & ~7;
   dim3 grid(nwg, zdim);
   static bool attr_set[2] = {false, false};
   if (p.taps == 1) {
-    auto kfn = gemm_big_kernel<T, BN, false>;
+    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, false>;
     if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = true; }
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   } else {
-    auto kfn = gemm_big_kernel<T, BN, true>;
+    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, true>;
     if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = true; }
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   }
@@ -332,24 +370,52 @@ static int launch_big(const GemmP& p, hipStream_t st) {
 }
 
 // Eligible: no split-K, N a multiple of 128 (wave tiles are 64 wide, GEGLU pairs stay inside one),
-// 16-byte-aligned fp32 epilogue vectors, and enough 256-row tiles to occupy the chip.
-bool gemm_big_eligible(const GemmP& p, int& bn) {
+// storage-dtype NHWC output, conv maps divisible into (BM/16) x 16 pixel patches, and enough tiles to
+// occupy the chip.  Configurations (BM x BN x BK): 256x256x32 (4-stage ring), 512x128x32,
+// 256x128x64 (3-stage ring, 128-byte rows = full cache lines per DMA lane group), 256x128x32.
+struct BigCfg { int bm, bn, bk, occ; };
+static bool big_cfg_ok(const GemmP& p, const BigCfg& c) {
+  if ((p.N % c.bn) != 0 || (p.K % c.bk) != 0 || (p.Cin % c.bk) != 0) return false;
+  if (p.K / c.bk < 4) return false;
+  if (p.taps == 9 && (p.Wo % 16 != 0 || p.Ho % (c.bm / 16) != 0)) return false;
+  const long long z = p.batch > 1 ? p.batch : 1;
+  return (long long)((p.M + c.bm - 1) / c.bm) * (p.N / c.bn) * z >= 192;
+}
+
+bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   static const char* off = getenv("DFW_GEMM_NOBIG");
+  static const char* force = getenv("DFW_BIG_CFG");   // experiments: "256x128x64"
   if (off) return false;
-  if (p.splitk > 1 || (p.N % 128) != 0 || (p.K % 32) != 0 || p.K < 128) return false;
-  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE) return false;   // slim epilogue: NHWC storage dtype
-  if (p.taps == 9 && (p.Wo % 16 != 0 || p.Ho % 16 != 0)) return false;  // 16x16 pixel tiles
-  bn = (p.N % 256) == 0 ? 256 : 128;
-  const long long tiles = (long long)((p.M + 255) / 256) * (p.N / bn) * (p.batch > 1 ? p.batch : 1);
-  return tiles >= 192;
+  if (p.splitk > 1 || (p.N % 128) != 0) return false;
+  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE) return false;
+  if (force) {
+    BigCfg c;
+    c.occ = 1;
+    if (sscanf(force, "%dx%dx%dx%d", &c.bm, &c.bn, &c.bk, &c.occ) >= 3 && big_cfg_ok(p, c)) {
+      bm = c.bm; bn = c.bn; bk = c.bk + (c.occ == 2 ? 1000 : 0);
+      return true;
+    }
+  }
+  static const BigCfg wide[] = {{256, 256, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
+  static const BigCfg narrow[] = {{512, 128, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
+  const BigCfg* list = (p.N % 256) == 0 ? wide : narrow;
+  for (int i = 0; i < 3; ++i)
+    if (big_cfg_ok(p, list[i])) {
+      bm = list[i].bm; bn = list[i].bn; bk = list[i].bk;
+      return true;
+    }
+  return false;
 }
 
 int launch_gemm_big(const GemmP& p, hipStream_t st) {
-  int bn = 0;
-  if (!gemm_big_eligible(p, bn)) return DFW_ESHAPE;
+  int bm = 0, bn = 0, bk = 0;
+  if (!gemm_big_eligible(p, bm, bn, bk)) return DFW_ESHAPE;
   const bool bf = p.dtype_bf16 != 0;
-  if (bn == 256) return bf ? launch_big<__bf16, 256>(p, st) : launch_big<_Float16, 256>(p, st);
-  return bf ? launch_big<__bf16, 128>(p, st) : launch_big<_Float16, 128>(p, st);
+  if (bk > 1000) return bf ? launch_big<__bf16, 256, 128, 32, 3, 2>(p, st) : launch_big<_Float16, 256, 128, 32, 3, 2>(p, st);
+  if (bm == 256 && bn == 256) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1>(p, st);
+  if (bm == 512) return bf ? launch_big<__bf16, 512, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1>(p, st);
+  if (bk == 64) return bf ? launch_big<__bf16, 256, 128, 64, 3, 1>(p, st) : launch_big<_Float16, 256, 128, 64, 3, 1>(p, st);
+  return bf ? launch_big<__bf16, 256, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 128, 32, 4, 1>(p, st);
 }
 
 }  // namespace dfw

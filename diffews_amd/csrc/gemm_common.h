@@ -81,6 +81,6 @@ struct TileC {
 };
 
 int launch_gemm_big(const GemmP& p, hipStream_t st);  // gemm_big.hip
-bool gemm_big_eligible(const GemmP& p, int& bn);
+bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk);
 
 }  // namespace dfw
