@@ -273,6 +273,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
 
   auto compute = [&](int slot) {
     const char* buf = smem + slot * STAGE;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       typename Tr<T>::v8 fa[MB], fw[NB];
