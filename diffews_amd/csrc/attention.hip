@@ -15,6 +15,8 @@
 //                   fragments come from the row-major V tile via ds_read_b64_tr_b16.
 // fp32 accumulation and fp32 softmax statistics throughout.
 #include "common.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 namespace dfw {
 
@@ -273,6 +275,226 @@ __global__ __launch_bounds__(256) void fsa_kernel(const FsaP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// v2: same mathematics and register layout as fsa_kernel, different data movement:
+//   * NW = 8 (or 4) waves share every K/V tile: 256 (128) query rows per workgroup;
+//   * K/V tiles arrive by LDS-DMA into a ring of S = 4 stages (K 8 KB + V 8 KB each), issued from
+//     inline asm so three tiles stay in flight across the barriers (counted s_waitcnt vmcnt);
+//   * the bank swizzles are applied on the DMA source address (LDS is written linearly);
+//   * one barrier per key tile, no register staging, no ds_write.
+template <typename T, int NW, int QB>
+__global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 ? 2 : 4) * NW / 8 : 1) void fsa_ring_kernel(const FsaP p) {
+  // QB = 32-row query blocks per wave: with QB = 2 the two blocks are independent dependency chains
+  // in one instruction stream, so one block's softmax VALU work overlaps the other's MFMAs, and
+  // every K / V fragment read from LDS feeds two MFMAs.
+  constexpr int KT = 64, S = 4;
+  constexpr int TILE = KT * 128;            // bytes of one K (or V) tile
+  constexpr int STAGE = 2 * TILE;
+  constexpr int DPS = 16 / NW;              // DMA wave-instructions per stage per wave (K + V)
+  __shared__ __attribute__((aligned(16))) char smem[S * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (NW * 32 * QB) + wave * (32 * QB);
+  const uint32_t lds0 = lds_addr(smem);
+
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes);
+  const u32x4 rk = make_srd(p.k, p.k_bytes), rv = make_srd(p.v, p.v_bytes);
+  const u32x4 rkb = make_srd(p.kb ? p.kb : p.k, p.kb ? p.kb_bytes : 0u);
+  const u32x4 rvb = make_srd(p.vb ? p.vb : p.v, p.vb ? p.vb_bytes : 0u);
+
+  typename Tr<T>::v8 qf[QB][4];
+#pragma unroll
+  for (int g = 0; g < QB; ++g) {
+    const int qrow = q0 + g * 32 + lr;
+    const uint32_t base = qrow < p.n_q
+        ? (uint32_t)(((size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + lh * 8) * sizeof(T)) : kOOB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[g][s] = as_v8<T>(buf_load16(rq, base + (uint32_t)(s * 32)));
+  }
+
+  // ---- loader: wave-instruction j of a wave covers tile rows (j*NW + wave)*8 .. +8 of K, then of V;
+  // lane -> row + (lane>>3), LDS slot lane&7; source chunk = slot ^ swizzle(row)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int tiles_own = (p.n_kv + KT - 1) / KT;
+  const int tiles_bank = p.nshot > 0 ? (p.n_bank + KT - 1) / KT : 0;
+  const int ntiles = tiles_own + p.nshot * tiles_bank;
+  int ld_seg = 0, ld_tt = 0;   // segment / tile-in-segment of the next tile to load
+  auto issue = [&](int st) {
+    const uint32_t dst = lds0 + (uint32_t)st * STAGE;
+    const int key0 = ld_tt * KT;
+    const bool own = ld_seg == 0;
+    const int nseg = own ? p.n_kv : p.n_bank;
+    const size_t img = own ? (size_t)b : (size_t)b * p.nshot + (ld_seg - 1);
+    const size_t kbase = img * (own ? p.k_bs : p.kb_bs) + head * 64;
+    const size_t vbase = img * (own ? p.v_bs : p.vb_bs) + head * 64;
+    const int ldk = own ? p.ldk : p.ldkb, ldv = own ? p.ldv : p.ldvb;
+    u32x4 srk, srv;   // descriptor of this tile's source, forced back into SGPRs after the select
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      srk[e] = __builtin_amdgcn_readfirstlane(own ? rk[e] : rkb[e]);
+      srv[e] = __builtin_amdgcn_readfirstlane(own ? rv[e] : rvb[e]);
+    }
+#pragma unroll
+    for (int j = 0; j < DPS / 2; ++j) {
+      const int row = (j * NW + wave) * 8 + lrow;
+      const int key = key0 + row;
+      const bool ok = key < nseg;
+      const int ck = slot ^ ((row >> 1) & 7);
+      const int cv = slot ^ (((row >> 1) & 1) << 2);
+      const uint32_t ko = ok ? (uint32_t)((kbase + (size_t)key * ldk + ck * 8) * sizeof(T)) : kOOB;
+      const uint32_t vo = ok ? (uint32_t)((vbase + (size_t)key * ldv + cv * 8) * sizeof(T)) : kOOB;
+      dma16(srk, ko, dst + (uint32_t)(j * NW + wave) * 1024u);
+      dma16(srv, vo, dst + TILE + (uint32_t)(j * NW + wave) * 1024u);
+    }
+    const int lim = own ? tiles_own : tiles_bank;
+    if (++ld_tt == lim) { ld_tt = 0; ++ld_seg; }
+  };
+
+  uint32_t kr[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int row = kb * 32 + lr;
+    kr[kb] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+
+  f32x16 o[QB][2];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int g = 0; g < QB; ++g) {
+    m_run[g] = -1e30f;
+    l_run[g] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[g][d][r] = 0.f;
+  }
+
+  int issued = 0;
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i)
+    if (issued < ntiles) { issue(i); ++issued; }
+  int c_tt = 0, c_own = 1;  // compute-side tile-in-segment / own-segment flag
+  for (int t = 0; t < ntiles; ++t) {
+    const int younger = issued - t - 1;
+    if (younger >= 2) wait_vm<2 * DPS>();
+    else if (younger == 1) wait_vm<DPS>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < ntiles) { issue(issued & (S - 1)); ++issued; }
+    const char* kbuf = smem + (t & (S - 1)) * STAGE;
+    const char* vbuf = kbuf + TILE;
+    const int nvalid = (c_own ? p.n_kv : p.n_bank) - c_tt * KT;
+    if (++c_tt == (c_own ? tiles_own : tiles_bank)) { c_tt = 0; c_own = 0; }
+
+    // ---- S^T = K . Q^T  (each K fragment feeds QB MFMAs)
+    f32x16 s[QB][2];
+#pragma unroll
+    for (int g = 0; g < QB; ++g)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[g][kb][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        typename Tr<T>::v8 kf = as_v8<T>(*(const i32x4*)(kbuf + (kr[kb] ^ (ss << 5))));
+#pragma unroll
+        for (int g = 0; g < QB; ++g) s[g][kb] = Tr<T>::mfma(kf, qf[g][ss], s[g][kb]);
+      }
+    typename Tr<T>::v8 pf[QB][4];
+#pragma unroll
+    for (int g = 0; g < QB; ++g) {
+      if (nvalid < KT) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= nvalid) s[g][kb][r] = -INFINITY;
+          }
+      }
+      // ---- online softmax (row = this lane's q; its other 32 keys live in lane^32)
+      float mt = s[g][0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[g][kb][r]);
+      mt = half_swap_max(mt);
+      const float m_new = fmaxf(m_run[g], mt);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[g] - m_new) * p.c);
+      const float mc = m_new * p.c;
+      m_run[g] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[g][kb][r] * p.c - mc);
+          s[g][kb][r] = e;
+          psum += e;
+        }
+      l_run[g] = l_run[g] * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[g][kb * 2 + t2][j] = (T)s[g][kb][8 * t2 + j];
+    }
+
+    // ---- O^T += V^T . P^T  (each V^T fragment feeds QB MFMAs)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int keybase = kb * 32 + 16 * t2 + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int dcol = d * 32 + 16 * tg + 4 * tp;
+          const int row0 = keybase + tq, row1 = row0 + 8;
+          const uint32_t a0 = row0 * 128 + ((((dcol >> 3) ^ (((row0 >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1);
+          const uint32_t a1 = row1 * 128 + ((((dcol >> 3) ^ (((row1 >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1);
+          typename Tr<T>::v4 lo = lds_tr_read<T>(vbuf + a0);
+          typename Tr<T>::v4 hi = lds_tr_read<T>(vbuf + a1);
+          typename Tr<T>::v8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+#pragma unroll
+          for (int g = 0; g < QB; ++g) o[g][d] = Tr<T>::mfma(vf, pf[g][kb * 2 + t2], o[g][d]);
+        }
+      }
+  }
+
+#pragma unroll
+  for (int g = 0; g < QB; ++g) {
+  const float l_tot = half_swap_sum(l_run[g]);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + g * 32 + lr;
+  if (qrow < p.n_q) {
+    char* ob = p.out + ((size_t)b * p.o_bs + (size_t)qrow * p.ldo + head * 64) * sizeof(T);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[g][d][4 * gg + e] * inv;
+        *(i32x2*)(ob + (d * 32 + 8 * gg + 4 * lh) * sizeof(T)) = pack4<T>(v);
+      }
+  }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cross-attention over a short context (L keys): one thread per query row, K/V of the (batch, head)
 // staged in LDS as fp32, online softmax in registers.
 struct XaP {
@@ -367,10 +589,30 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldkb = a->ldkb; p.ldvb = a->ldvb; p.ldo = a->ldo;
   p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.kb_bs = a->kb_bs; p.vb_bs = a->vb_bs; p.o_bs = a->o_bs;
   p.c = a->scale * 1.4426950408889634f;
-  dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  static const char* v1 = getenv("DFW_FSA_V1");
+  const bool bf = a->dtype == DFW_BF16;
+  if (v1) {
+    dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
+    if (bf) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  } else {
+    static const char* var = getenv("DFW_FSA_VARIANT");   // experiments: "8x1", "4x2", "4x1"
+    int nw = 8, qb = 1;
+    if (var) sscanf(var, "%dx%d", &nw, &qb);
+    if (a->n_q <= 128) { nw = 4; qb = 1; }
+    dim3 grid((a->n_q + nw * 32 * qb - 1) / (nw * 32 * qb), a->heads, a->batch);
+    if (nw == 8) {
+      if (bf) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 8, 1>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 8, 1>), grid, dim3(512), 0, st, p);
+    } else if (qb == 2) {
+      if (bf) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 4, 2>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 4, 2>), grid, dim3(256), 0, st, p);
+    } else {
+      if (bf) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 4, 1>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 4, 1>), grid, dim3(256), 0, st, p);
+    }
+  }
   DFW_CHECK_LAUNCH();
   return 0;
 }

@@ -76,6 +76,36 @@ __device__ __forceinline__ i32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t b
 }
 constexpr uint32_t kOOB = 0x80000000u;  // always >= num_records (tensors are < 2 GiB, checked on host)
 
+// ---- LDS-DMA from inline asm (invisible to hipcc's waitcnt bookkeeping on purpose: stages stay in
+// flight across barriers and are retired by counted waits).
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 make_srd(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B -> LDS [m0 .. m0 + 1 KiB), out-of-range lanes
+// write zeros.  M0 is written in the same statement that uses it (hipcc does not preserve it around
+// asm); s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
+__device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t lds_byte) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_byte), "v"(voff), "s"(srd) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

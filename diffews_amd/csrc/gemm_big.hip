@@ -22,30 +22,6 @@
 
 namespace dfw {
 
-using u32x4 = unsigned __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ u32x4 make_srd(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)p;
-  u32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-  r[2] = __builtin_amdgcn_readfirstlane(bytes);
-  r[3] = 0x00020000u;
-  return r;
-}
-
-// One LDS-DMA wave-instruction: 64 lanes x 16 B -> LDS [m0 .. m0 + 1 KiB).  M0 is written in the
-// same statement that uses it (hipcc does not preserve it around asm); s_nop covers the
-// SALU-write-M0 -> LDS-DMA hazard.  Invisible to hipcc's waitcnt bookkeeping by design.
-__device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t lds_byte) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(lds_byte), "v"(voff), "s"(srd) : "memory");
-}
-
-template <int N> __device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
-
 template <typename T, int BM, int BN, int BK, int S, int OCC, bool CONV>
 __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   // S ring stages (S-1 in flight); OCC workgroups per CU (2 * OCC waves per SIMD)
@@ -63,7 +39,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 31, lh = lane >> 5;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds0 = lds_addr(smem);
 
   // ---- persistent tile walk (same XCD-contiguous order as gemm.hip)
   const int ntiles = p.ntm * p.ntn;
