@@ -107,7 +107,17 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact (erf) GELU as diffusers' GEGLU uses (F.gelu default), with erf from Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the storage dtype's rounding): the library erff costs ~3x more VALU
+// and made the GEGLU GEMM epilogue longer than its K loop.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float y = 1.0f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
