@@ -133,15 +133,25 @@ def main():
     if world != args.gpus and world > 1:
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # DFW_DIST_BACKEND=gloo + DFW_ONE_DEVICE=1: rehearse the N>1 control flow with every rank on
+    # cuda:0 of a one-GPU box (RCCL refuses two ranks on one device); never used for a bench line.
+    backend = os.environ.get("DFW_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("DFW_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from diffews_amd import build, episodes
     from diffews_amd.metrics import AverageMeter, fold_class_ids
-    build.build()
+    if rank == 0:
+        build.build()   # no-op when the in-tree .so is current; never raced by the other ranks
+    if world > 1:
+        dist.barrier()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, blobs = build_pipeline(dtype, tiny=args.tiny)
 
@@ -214,8 +224,17 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         n, fl, t = dom[1]
         ach = fl / t / 1e12
+        # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE,
+        # WRITE_SIZE; they cannot share a pass with each other or with timing) summarised by
+        # profiles/summarize_pmc.py with the gfx950 correction (2*FETCH_SIZE + WRITE_SIZE) KiB.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = round(json.load(f)[dom[0]]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         roof = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches_per_step=n,
+                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic, launches_per_step=n,
                     avg_launch_us=round(t / n * 1e6, 2), flops_per_launch=fl / n,
                     gemm_time_share_of_step=round(tot_t / (elapsed / args.steps), 3))
     cpu = None

@@ -7,16 +7,27 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffews_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "attention.hip", "norm.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "attention.hip", "norm.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-unused-value"]
 
 
+def _src_hash():
+    """Content hash of every kernel source + the ABI header + the flags (mtimes do not survive the
+    snapshot copy to the GPU box, contents do)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "diffews_hip.h")]
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.isfile(LIB):
+    if not os.path.isfile(LIB) or not os.path.isfile(LIB + ".srchash"):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "diffews_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(LIB + ".srchash") as f:
+        return f.read().strip() != _src_hash()
 
 
 def build(force=False, verbose=False):
@@ -43,6 +54,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(LIB + ".srchash", "w") as f:
+        f.write(_src_hash())
     return LIB
 
 

@@ -207,6 +207,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         }
         continue;
       }
+      if (p.splitk <= 1 && (p.N & 3) == 0) {
+        const int img = p.rowbias ? (CONV && p.tw ? img_ : m / p.rows_per_img) : 0;
+        epi_block<T, NB>(p, Cb, m, img, c.n0 + wn * WTN + 4 * lh, acc[i]);
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -448,7 +453,11 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   int rc = fill_params(a, p, esz);
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
-  int big_bm = 0, big_bn = 0, big_bk = 0;
+  int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
+  if (conv_halo_eligible(p, halo_bn)) {
+    snprintf(buf, n, "conv_halo_kernel<%s,256,%d>", a->dtype == DFW_BF16 ? "bf16" : "f16", halo_bn);
+    return 0;
+  }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
     snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn, big_bk,
              a->taps == 9 ? "conv" : "lin");
@@ -475,7 +484,8 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
     if (!a->workspace || a->workspace_bytes < (size_t)p.splitk * p.M * p.N * sizeof(float)) return DFW_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  int big_bm = 0, big_bn = 0, big_bk = 0;
+  int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
+  if (conv_halo_eligible(p, halo_bn)) return launch_conv_halo(p, st);
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
 }

@@ -74,6 +74,60 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
   }
 }
 
+// Epilogue of one 32-row block of a lane (N % 4 == 0): the lane owns row m and, for each of its NB
+// 32-column blocks, four groups of 4 consecutive channels n = ncol0 + 32*j + 8*g.
+// Every load (bias, per-image row bias, residual) is issued BEFORE the first store: on gfx9xx vmcnt
+// counts stores too and retires in order, so a load issued after a store waits for that store's
+// round trip -- interleaved load/store pairs made the epilogue as long as 10-12 K-steps per tile.
+template <typename T, int NB, bool SLIM = false>   // SLIM: storage-dtype NHWC output, no activation
+__device__ __forceinline__ void epi_block(const GemmP& p, char* Cb, int m, int img, int ncol0,
+                                          const f32x16 (&a)[NB]) {
+  f32x4 add[NB][4];
+  i32x2 res[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ncol0 + 32 * j + 8 * g;
+      const bool ok = n < p.N;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && ok) b = *(const f32x4*)(p.bias + n);
+      if (p.rowbias && ok) {
+        const f32x4 r = *(const f32x4*)(p.rowbias + (size_t)img * p.ldrb + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] += r[e];
+      }
+      add[j][g] = b;
+      res[j][g] = i32x2{0, 0};
+      if (p.residual && ok) res[j][g] = *(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T));
+    }
+  const int rimg = (!SLIM && p.out_mode == DFW_OUT_NCHW_F32) ? m / p.rows_per_img : 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ncol0 + 32 * j + 8 * g;
+      if (n >= p.N) continue;
+      float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.residual) unpack4<T>(res[j][g], r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (a[j][4 * g + e] + add[j][g][e] + r[e]) * p.out_scale;
+        if (!SLIM && p.act == DFW_ACT_SILU) v[e] = silu_f(v[e]);
+      }
+      if (SLIM || p.out_mode == DFW_OUT_T) {
+        *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
+      } else if (p.out_mode == DFW_OUT_F32) {
+        const f32x4 o = {v[0], v[1], v[2], v[3]};
+        *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = o;
+      } else {
+        const int pix = m - rimg * p.rows_per_img;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ((float*)Cb)[((size_t)rimg * p.N + n + e) * p.rows_per_img + pix] = v[e];
+      }
+    }
+}
+
 // Tile coordinates of one output tile (uniform per workgroup).
 struct TileC {
   int m0, n0;                 // first output row (linear tiles) / first output channel
@@ -82,5 +136,7 @@ struct TileC {
 
 int launch_gemm_big(const GemmP& p, hipStream_t st);  // gemm_big.hip
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk);
+int launch_conv_halo(const GemmP& p, hipStream_t st);  // conv_halo.hip
+bool conv_halo_eligible(const GemmP& p, int& bn);
 
 }  // namespace dfw
