@@ -442,6 +442,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
   p.dtype_bf16 = a->dtype == DFW_BF16;
+  p.gn_partial = a->gn_partial; p.gn_groups = a->gn_groups; p.gn_chunks = 0;
   if (p.splitk > p.nk) p.splitk = p.nk;
   plan_gemm(p, p.plan_bm, p.plan_bn);
   return 0;
@@ -466,6 +467,13 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>%s", a->dtype == DFW_BF16 ? "bf16" : "f16", p.plan_bm, p.plan_bn,
            a->taps == 9 ? "conv" : "lin", p.splitk > 1 ? "+splitk" : "");
   return 0;
+}
+
+extern "C" int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a) {
+  GemmP p;
+  int esz;
+  if (fill_params(a, p, esz)) return 0;
+  return gemm_big_gn_chunks(p);
 }
 
 extern "C" size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a) {

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   // round trip a lane holds 16 contiguous bytes and a store instruction covers 8 rows x 128 B of
   // whole cache lines -- half the store instructions, no partial-line writes.
   constexpr bool kStage = STAGE >= 8 * 4096;
-  auto epilogue = [&](const TileC& c, char* stg) {
+  auto epilogue = [&](const TileC& c, char* stg, int tile_id) {
+    float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;   // fused GroupNorm sums of this lane's channel pair
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       int oy_ = 0, ox_ = 0, img_ = 0;
@@ -234,6 +235,19 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
         }
       if constexpr (kStage) {
         // same wave wrote and reads this region: program order + the compiler's lgkmcnt wait suffice
+        if (p.gn_partial) {
+          // lane -> channel pair cp of the wave's 64 channels, half rh of the 32 staged rows
+          const int cp = lane & 31, rh = lane >> 5;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int r = rh * 16 + t;
+            const uint32_t w2 = *(const uint32_t*)(stg + r * 128 + (((cp >> 2) ^ (r & 7)) << 4) + (cp & 3) * 4);
+            typename Tr<T>::v4 pr = __builtin_bit_cast(typename Tr<T>::v4, i32x2{(int)w2, 0});
+            const float a0 = (float)pr[0], a1 = (float)pr[1];
+            gs0 += a0; gq0 += a0 * a0;
+            gs1 += a1; gq1 += a1 * a1;
+          }
+        }
         const int c16 = lane & 7;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -243,6 +257,28 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
           const i32x4 val = *(const i32x4*)(stg + r * 128 + ((c16 ^ (r & 7)) << 4));
           if (m2 < p.M)
             *(i32x4*)(Cb + ((size_t)m2 * p.ldc + c.n0 + wn * 64 + c16 * 8) * sizeof(T)) = val;
+        }
+      }
+    }
+    if constexpr (kStage) {
+      if (p.gn_partial) {
+        // rows: other half-wave; channels: pairs -> groups (cpg/2 adjacent lanes); fixed order => deterministic
+        float s = gs0 + gs1, q = gq0 + gq1;
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        const int cpg = p.N / p.gn_groups, ppg = cpg >> 1;
+        for (int o = 1; o < ppg; o <<= 1) {
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        const int cp = lane & 31;
+        if (lane < 32 && (cp & (ppg - 1)) == 0) {
+          const int tm = tile_id / p.ntn;
+          const int chunk = (tm - c.img * p.tpi) * WGM + wm;
+          const int grp = (c.n0 + wn * 64 + 2 * cp) / cpg;
+          float* o2 = p.gn_partial + (((size_t)c.img * p.gn_chunks + chunk) * p.gn_groups + grp) * 2;
+          o2[0] = s;
+          o2[1] = q;
         }
       }
     }
@@ -310,7 +346,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
       asm volatile("" ::: "memory");
       stg = smem + (rs == 0 ? S - 1 : rs - 1) * STAGE + wave * 4096;
     }
-    epilogue(ct, stg);
+    epilogue(ct, stg, tile0 + ti * nxb);
     if (has_next) ct = tile_coords(tile0 + (ti + 1) * nxb);
     else ws = rs;
   }
@@ -321,6 +357,8 @@ static int launch_big(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.ntm = (p.M + BM - 1) / BM;
   q.ntn = (p.N + BN - 1) / BN;
+  q.gn_chunks = p.gn_partial ? gemm_big_gn_chunks(p) : 0;
+  if (q.gn_chunks == 0) q.gn_partial = nullptr;
   q.tw = 0; q.tw_log2 = 0; q.tpr = 0; q.tpi = 0;
   if (p.taps == 9) {
     q.tw = 16; q.tw_log2 = getenv("DFW_HACK_SKIPA") ? 99 : 4;   // 99: timing experiment, A tiles read as zeros
@@ -383,6 +421,18 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
       return true;
     }
   return false;
+}
+
+int gemm_big_gn_chunks(const GemmP& p) {
+  int bm = 0, bn = 0, bk = 0;
+  if (p.gn_groups <= 0 || p.taps != 9 || p.geglu || !gemm_big_eligible(p, bm, bn, bk)) return 0;
+  if (bk > 1000) return 0;                                        // 2-workgroup variant has no staging
+  if ((size_t)(bm + bn) * bk * 2 < 8 * 4096) return 0;            // staged epilogue needs a 32 KiB slot
+  if (p.N % p.gn_groups) return 0;
+  const int cpg = p.N / p.gn_groups;
+  if (cpg < 4 || cpg > 64 || (cpg & (cpg - 1))) return 0;         // groups must tile the 64-channel wave tiles
+  const int wgm = 8 / (bn / 64);
+  return (p.Wo / 16) * (p.Ho / (bm / 16)) * wgm;
 }
 
 int launch_gemm_big(const GemmP& p, hipStream_t st) {

@@ -217,18 +217,25 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   if (lds1 > 64 * 1024) return DFW_ESHAPE;
   const dim3 gridf((a->B * a->groups + 3) / 4);
   dim3 grid(chunks, a->B);
+  const bool pre = a->pre_partial != nullptr && a->pre_chunks > 0;
+  if (pre) {   // statistics were fused into the conv that produced x
+    p.part = const_cast<float*>(a->pre_partial);
+    p.chunks = a->pre_chunks;
+  }
+  GnP pa = p;  // apply pass keeps its own pixel chunking
+  pa.chunks = chunks;
   if (a->dtype == DFW_BF16) {
-    hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, dim3(threads), lds1, st, p);
+    if (!pre) hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, p);
+    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, pa);
   } else {
-    hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, dim3(threads), lds1, st, p);
+    if (!pre) hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, p);
+    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, pa);
   }
   DFW_CHECK_LAUNCH();
   return 0;

@@ -125,7 +125,7 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
-            out_nchw_f32=False, out_scale=1.0, splitk=None):
+            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling."""
@@ -160,7 +160,18 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else L.OUT_T
     a.splitk = 0 if splitk is None else splitk
     a.batch, a.dtype = 1, _dt(x)
+    stats = None
+    if gn_groups and not out_nchw_f32:
+        # fused GroupNorm statistics of the output, when the planned kernel supports them
+        a.gn_groups = gn_groups
+        chunks = L.lib().dfw_gemm_gn_chunks(C.byref(a))
+        if chunks > 0:
+            part = torch.empty(B, chunks, gn_groups, 2, dtype=torch.float32, device=x.device)
+            a.gn_partial = part.data_ptr()
+            stats = (part, chunks, gn_groups)
     _gemm_call(a)
+    if stats is not None:
+        out._gn_stats = stats   # consumed by groupnorm(out, ...) -- valid while `out` is not modified
     return out
 
 
@@ -215,6 +226,9 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False):
     a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
     a.B, a.HW, a.C, a.groups, a.ldx, a.ldy = B, HW, Cc, groups, Cc, Cc
     a.eps, a.silu, a.dtype = eps, int(silu), _dt(x)
+    st = getattr(x, "_gn_stats", None)
+    if st is not None and st[2] == groups and st[0].shape[0] == B:
+        a.pre_partial, a.pre_chunks = st[0].data_ptr(), st[1]
     lib = L.lib()
     nbytes = lib.dfw_groupnorm_workspace_bytes(C.byref(a))
     if nbytes == 0:

@@ -55,12 +55,12 @@ class _Resnet:
         if self.has_temb:
             o, c = self.temb_slice
             rb = tproj[:, o:o + c]
-        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1, rowbias=rb)
+        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1, rowbias=rb, gn_groups=self.groups)
         h = ops.groupnorm(h, self.g2, self.b2, self.groups, self.eps, silu=True)
         sc = x
         if self.ws is not None:
             sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
-        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc)
+        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups)
 
 
 class _Transformer:

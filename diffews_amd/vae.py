@@ -31,12 +31,12 @@ class _VaeResnet:
     def __call__(self, x):
         B, H, W, Cin = x.shape
         h = ops.groupnorm(x, self.g1, self.b1, self.groups, 1e-6, silu=True)
-        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1)
+        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1, gn_groups=self.groups)
         h = ops.groupnorm(h, self.g2, self.b2, self.groups, 1e-6, silu=True)
         sc = x
         if self.ws is not None:
             sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
-        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc)
+        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups)
 
 
 class _VaeAttention:
@@ -101,7 +101,7 @@ class _Encoder:
             for r in res:
                 h = r(h)
             if down is not None:  # F.pad(0,1,0,1) + conv stride 2 padding 0
-                h = ops.conv3x3(h, down.w, down.cout, bias=down.b, stride=2, pad=0)
+                h = ops.conv3x3(h, down.w, down.cout, bias=down.b, stride=2, pad=0, gn_groups=self.groups)
         h = self.mid(h)
         h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
         co = self.conv_out
@@ -136,7 +136,7 @@ class _Decoder:
             for r in res:
                 h = r(h)
             if up is not None:
-                h = ops.conv3x3(h, up.w, up.cout, bias=up.b, ups=True)
+                h = ops.conv3x3(h, up.w, up.cout, bias=up.b, ups=True, gn_groups=self.groups)
         h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
         co = self.conv_out
         return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True)  # [b, 3, H, W] fp32

@@ -73,6 +73,11 @@ typedef struct {
   int32_t act, geglu, out_mode, splitk;
   int32_t batch; int64_t strideA, strideW, strideC;
   int32_t dtype;
+  /* Optional fused GroupNorm statistics of the OUTPUT (the next op's GroupNorm input): when
+   * gn_partial != NULL the epilogue also writes per-(image, chunk, group) {sum, sum of squares}
+   * of the stored values, gn_partial[img][chunk][group][2] floats, chunk < dfw_gemm_gn_chunks().
+   * Only kernels/shapes for which dfw_gemm_gn_chunks() returns > 0 support it. */
+  float* gn_partial; int32_t gn_groups;
 } dfw_gemm_args;
 
 int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);
@@ -80,6 +85,9 @@ size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a);
 /* Which kernel instantiation dfw_gemm would launch for these arguments, e.g.
  * "gemm_kernel<bf16,128,128,conv>" (used by bench.py to attribute time per kernel). */
 int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n);
+/* Chunks per image of the fused GroupNorm partial sums this call would emit for gn_groups groups
+ * (0: unsupported for this shape / kernel; run dfw_groupnorm's own statistics pass instead). */
+int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a);
 
 /*
  * KV-fusion self-attention (the DiffewS-specific op): out = softmax(q [k_own ; k_bank]^T * scale) [v_own ; v_bank]
@@ -130,6 +138,9 @@ typedef struct {
   float eps;
   int32_t silu;
   int32_t dtype;
+  /* Optional: partial sums already produced by the conv that wrote x (dfw_gemm_args.gn_partial),
+   * [B][pre_chunks][groups][2] floats; the statistics pass over x is then skipped. */
+  const float* pre_partial; int32_t pre_chunks;
 } dfw_groupnorm_args;
 
 int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream);

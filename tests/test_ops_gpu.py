@@ -127,6 +127,24 @@ def test_conv3x3_big_tiles(ops, dtype, B, H, W, Cin, Cout, ups):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 128, 128, 64, 256), (3, 128, 128, 64, 128), (2, 128, 192, 128, 512)])
+def test_conv_fused_groupnorm_stats(ops, dtype, B, H, W, Cin, Cout):
+    """GroupNorm statistics emitted by the producing conv's epilogue == a separate statistics pass."""
+    from diffews_amd.packing import pack_conv3x3
+    x = rnd((B, H, W, Cin), dtype, 1).cuda()
+    w = pack_conv3x3(rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)).cuda()
+    bias = torch.randn(Cout).cuda()
+    g, b = (torch.randn(Cout) * 0.2 + 1).cuda(), (torch.randn(Cout) * 0.2).cuda()
+    y = ops.conv3x3(x, w, Cout, bias=bias, gn_groups=32)
+    assert getattr(y, "_gn_stats", None) is not None, "fused statistics expected for this shape"
+    fused = ops.groupnorm(y, g, b, 32, 1e-6, silu=True)
+    plain = ops.groupnorm(y.clone(), g, b, 32, 1e-6, silu=True)          # clone drops the attribute
+    ref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, g, b, eps=1e-6)).permute(0, 2, 3, 1)
+    assert rel(fused, ref) < TOL[dtype] and rel(plain, ref) < TOL[dtype]
+    assert rel(fused, plain) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_big_tiles(ops, dtype):
     from diffews_amd.packing import pack_geglu
     for M, N, K in [(49152, 256, 128), (24576, 384, 320), (50000, 128, 64 * 3)]:
