@@ -74,7 +74,7 @@ typedef struct {
   int32_t batch; int64_t strideA, strideW, strideC;
   int32_t dtype;
   /* Optional fused GroupNorm statistics of the OUTPUT (the next op's GroupNorm input): when
-   * gn_partial != NULL the epilogue also writes per-(image, chunk, group) {sum, sum of squares}
+   * gn_partial != NULL the epilogue also writes per-(image, chunk, group) (sum, sum of squares)
    * of the stored values, gn_partial[img][chunk][group][2] floats, chunk < dfw_gemm_gn_chunks().
    * Only kernels/shapes for which dfw_gemm_gn_chunks() returns > 0 support it. */
   float* gn_partial; int32_t gn_groups;
