@@ -87,6 +87,7 @@ class _Transformer:
         self.w_ff2, self.b_ff2 = w(b + "ff.net.2.weight"), f(b + "ff.net.2.bias")
         self.k_bank = None
         self.v_bank = None
+        self.kv_slice = (0, 2 * self.w_q2.shape[0])   # column range in the fused prompt-K/V buffer
 
     def clear_bank(self):
         self.k_bank = None
@@ -125,7 +126,13 @@ class _Transformer:
         # --- attn2: cross-attention on the prompt tokens
         ln = ops.layernorm(t, *self.ln[1])
         q2 = ops.linear(ln, self.w_q2).view(B, N, C)
-        kv2 = ops.linear(ehs2d, self.w_kv2).view(B, L_ctx, 2 * C)
+        # prompt K/V of all 16 layers come from ONE GEMM per forward (MyUNet2DConditionModel._prompt_kv);
+        # this layer's [B, L, 2C] slice is a strided view of that buffer
+        o, kv_all = self.kv_slice[0], ehs2d
+        if isinstance(kv_all, tuple):
+            kv2 = kv_all[1].view(B, L_ctx, -1)[..., o:o + 2 * C]
+        else:
+            kv2 = ops.linear(ehs2d, self.w_kv2).view(B, L_ctx, 2 * C)
         ca = ops.cross_attention(q2, kv2[..., :C], kv2[..., C:], heads)
         t = ops.linear(ca.view(-1, C), self.w_o2, bias=self.b_o2, residual=t)
         # --- GEGLU feed-forward
@@ -222,6 +229,13 @@ class MyUNet2DConditionModel:
             off += r.cout
         self.tp_w = torch.cat(ws, 0).to(dev, dt).contiguous()
         self.tp_b = torch.cat(bs, 0).float().to(dev)
+        # prompt K/V projections (attn2.to_k / to_v) of every transformer layer fused into one GEMM
+        kvw, off = [], 0
+        for t in self._transformers():
+            kvw.append(t.w_kv2)
+            t.kv_slice = (off, t.w_kv2.shape[0])
+            off += t.w_kv2.shape[0]
+        self.kv_w_all = torch.cat(kvw, 0).contiguous()
 
     def _resnets_with_prefix(self):
         for i, blk in enumerate(self.down):
@@ -346,6 +360,8 @@ class MyUNet2DConditionModel:
         return out[n_ref:]
 
     def _trunk(self, x, tproj, ehs2d, L_ctx, n_ref, out_scale):
+        # all layers' prompt K/V in one launch: [B*L, sum(2C)]; layers take column slices
+        ehs2d = (ehs2d, ops.linear(ehs2d, self.kv_w_all))
         # ---- 3. down (U:1153-1175)
         skips = [x]
         for blk in self.down:
