@@ -145,6 +145,48 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) 
   return r;
 }
 
+// Row held in registers (L <= 4096, L % 4 == 0): one read of the fp32 scores instead of three.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* x, T* y, int L, float c) {
+  __shared__ float red[4];
+  const f32x4* xr = (const f32x4*)(x + (size_t)blockIdx.x * L);
+  T* yr = y + (size_t)blockIdx.x * L;
+  const int nv = L >> 2;
+  f32x4 v[4];
+  float m = -1e30f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = threadIdx.x + 256 * i;
+    if (j < nv) {
+      v[i] = xr[j];
+      m = fmaxf(fmaxf(fmaxf(m, v[i][0]), fmaxf(v[i][1], v[i][2])), v[i][3]);
+    }
+  }
+  m = block_reduce(m, true, red);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = threadIdx.x + 256 * i;
+    if (j < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] = __builtin_amdgcn_exp2f((v[i][e] - m) * c);
+        s += v[i][e];
+      }
+    }
+  }
+  s = block_reduce(s, false, red);
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = threadIdx.x + 256 * i;
+    if (j < nv) {
+      float o[4] = {v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv};
+      *(i32x2*)(yr + 4 * j) = pack4<T>(o);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, T* y, int L, float c) {
   __shared__ float red[4];
@@ -293,9 +335,12 @@ extern "C" int dfw_softmax_rows(const float* x, void* y, int64_t rows, int32_t L
   if (!x || !y || rows <= 0 || L <= 0 || rows > 0x7fffffff) return DFW_EINVAL;
   const float c = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DFW_BF16) hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, st, x, (__bf16*)y, L, c);
-  else if (dtype == DFW_F16) hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, st, x, (_Float16*)y, L, c);
-  else return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  if (L <= 4096 && (L & 3) == 0) {
+    if (dtype == DFW_BF16) hipLaunchKernelGGL((softmax_rows_reg_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, st, x, (__bf16*)y, L, c);
+    else hipLaunchKernelGGL((softmax_rows_reg_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, st, x, (_Float16*)y, L, c);
+  } else if (dtype == DFW_BF16) hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, st, x, (__bf16*)y, L, c);
+  else hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, st, x, (_Float16*)y, L, c);
   DFW_CHECK_LAUNCH();
   return 0;
 }
