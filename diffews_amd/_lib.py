@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("stride", _i32), ("pad", _i32), ("ups", _i32), ("rows_per_img", _i32),
                 ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),
                 ("batch", _i32), ("strideA", _i64), ("strideW", _i64), ("strideC", _i64), ("dtype", _i32),
-                ("gn_partial", _vp), ("gn_groups", _i32)]
+                ("gn_partial", _vp), ("gn_groups", _i32), ("gn_in_coef", _vp), ("gn_in_silu", _i32)]
 
 
 class FsaArgs(C.Structure):
@@ -46,7 +46,7 @@ class XattnArgs(C.Structure):
 class GroupNormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("stats_ws", _vp), ("stats_ws_bytes", _sz),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("ldx", _i32), ("ldy", _i32),
-                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pre_partial", _vp), ("pre_chunks", _i32)]
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pre_partial", _vp), ("pre_chunks", _i32), ("coef_out", _vp)]
 
 
 class LayerNormArgs(C.Structure):
@@ -68,6 +68,7 @@ SYMBOLS = {
     "dfw_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
     "dfw_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _sz]),
     "dfw_gemm_gn_chunks": (_i32, [C.POINTER(GemmArgs)]),
+    "dfw_gemm_gn_input_ok": (_i32, [C.POINTER(GemmArgs)]),
     "dfw_fsa_attention": (_i32, [C.POINTER(FsaArgs), _vp]),
     "dfw_cross_attention": (_i32, [C.POINTER(XattnArgs), _vp]),
     "dfw_groupnorm": (_i32, [C.POINTER(GroupNormArgs), _vp]),

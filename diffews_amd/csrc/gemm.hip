@@ -443,6 +443,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
   p.dtype_bf16 = a->dtype == DFW_BF16;
   p.gn_partial = a->gn_partial; p.gn_groups = a->gn_groups; p.gn_chunks = 0;
+  p.gn_coef = a->gn_in_coef; p.gn_silu = a->gn_in_silu;
   if (p.splitk > p.nk) p.splitk = p.nk;
   plan_gemm(p, p.plan_bm, p.plan_bn);
   return 0;
@@ -456,7 +457,7 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   if (!buf || n == 0) return DFW_EINVAL;
   int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
   if (conv_halo_eligible(p, halo_bn)) {
-    snprintf(buf, n, "conv_halo_kernel<%s,256,%d>", a->dtype == DFW_BF16 ? "bf16" : "f16", halo_bn);
+    snprintf(buf, n, "conv_halo_kernel<%s,256,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", halo_bn, p.gn_coef ? ",gn_in" : "");
     return 0;
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
@@ -473,7 +474,16 @@ extern "C" int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a) {
   GemmP p;
   int esz;
   if (fill_params(a, p, esz)) return 0;
+  int halo_bn = 0;
+  if (conv_halo_eligible(p, halo_bn)) return conv_halo_gn_chunks(p);
   return gemm_big_gn_chunks(p);
+}
+
+extern "C" int32_t dfw_gemm_gn_input_ok(const dfw_gemm_args* a) {
+  GemmP p;
+  int esz;
+  if (fill_params(a, p, esz)) return 0;
+  return conv_halo_gn_input_ok(p) ? 1 : 0;
 }
 
 extern "C" size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a) {
@@ -494,6 +504,7 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
   if (conv_halo_eligible(p, halo_bn)) return launch_conv_halo(p, st);
+  if (p.gn_coef) return DFW_ESHAPE;   // no other kernel normalises its input
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
 }

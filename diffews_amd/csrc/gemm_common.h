@@ -17,6 +17,7 @@ struct GemmP {
   int nk, cpt, ntn, ntm;
   int plan_bm, plan_bn, dtype_bf16;
   float* gn_partial; int gn_groups, gn_chunks;   // fused GroupNorm partial sums of the output (optional)
+  const float* gn_coef; int gn_silu;             // fused GroupNorm(+SiLU) of the input (conv_halo only)
   int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
 };
 
@@ -139,6 +140,8 @@ int launch_gemm_big(const GemmP& p, hipStream_t st);  // gemm_big.hip
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk);
 int gemm_big_gn_chunks(const GemmP& p);   // > 0: the planned big kernel can emit GroupNorm partials
 int launch_conv_halo(const GemmP& p, hipStream_t st);  // conv_halo.hip
+int conv_halo_gn_chunks(const GemmP& p);
+bool conv_halo_gn_input_ok(const GemmP& p);
 bool conv_halo_eligible(const GemmP& p, int& bn);
 
 }  // namespace dfw

@@ -10,6 +10,7 @@ struct CsP {
   const float* x; const float* W; const float* bias; char* y;
   int B, Cin, H, Wd, Cout, taps, ldy, out_mode;
   float in_scale, out_scale;
+  int iters;   // conv_small8w: pixel groups per thread
 };
 
 template <typename T>
@@ -129,6 +130,82 @@ __global__ __launch_bounds__(256) void conv_small4_kernel(const CsP p) {
         for (int px = 0; px < 4; ++px) v[px] = (acc[px][o] + bs[o]) * p.out_scale;
         *(f32x4*)((float*)p.y + ((size_t)b * p.Cout + co0 + o) * HW + pix) = v;
       }
+  }
+}
+
+// NHWC-output variant: the 16 lanes of a pixel group own the 16 channel octets of a 128-channel block,
+// so every store instruction writes whole 256-byte pixel rows (the per-octet grid of conv_small4
+// scattered 16-byte pieces of each row over 16 workgroups and ran ~6x off the write roofline on the
+// VAE's 3 -> 128 conv_in at 512x512).  Weights of the channel block sit in LDS as [tap*cin][128].
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem_cs[];
+  float* ws = (float*)smem_cs;            // [tc][128]
+  float* bs = ws + TAPS * p.Cin * 128;    // [128]
+  const int cb0 = blockIdx.y * 128;
+  const int tc = TAPS * p.Cin;
+  for (int e = threadIdx.x; e < tc * 128; e += 256) {
+    const int o = e & 127, k = e >> 7;
+    ws[e] = (cb0 + o < p.Cout) ? p.W[(size_t)(cb0 + o) * tc + k] : 0.f;
+  }
+  if (threadIdx.x < 128) bs[threadIdx.x] = (p.bias && cb0 + threadIdx.x < p.Cout) ? p.bias[cb0 + threadIdx.x] : 0.f;
+  __syncthreads();
+  constexpr int NK = TAPS == 9 ? 3 : 1, PAD = TAPS == 9 ? 1 : 0;
+  const int HW = p.H * p.Wd, W8 = p.Wd >> 3;
+  const int oct = threadIdx.x & 15;
+  if (cb0 + oct * 8 >= p.Cout) return;
+  const long long nq = (long long)p.B * p.H * W8;
+  // thread = 8 adjacent pixels x 8 channels (each LDS weight read feeds 64 FMAs; with 4 pixels the
+  // LDS pipe was as busy as the VALU); p.iters pixel groups per thread amortise the weight staging
+  for (int it = 0; it < p.iters; ++it) {
+    const long long q = ((long long)blockIdx.x * p.iters + it) * 16 + (threadIdx.x >> 4);
+    if (q >= nq) return;
+    const int b = (int)(q / (p.H * W8)), rem = (int)(q - (long long)b * p.H * W8);
+    const int y = rem / W8, x0 = (rem - y * W8) * 8;
+    f32x2 acc[8][4];                       // [pixel][channel pair]: packed fp32 FMAs
+#pragma unroll
+    for (int px = 0; px < 8; ++px)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[px][o] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < NK; ++ky) {
+      const int iy = y + ky - PAD;
+      if ((unsigned)iy >= (unsigned)p.H) continue;
+      for (int c = 0; c < p.Cin; ++c) {
+        const float* row = p.x + ((size_t)(b * p.Cin + c) * p.H + iy) * p.Wd;
+        const f32x4 m0 = *(const f32x4*)(row + x0), m1 = *(const f32x4*)(row + x0 + 4);
+        float in[10];
+        in[0] = (PAD && x0 > 0) ? row[x0 - 1] * p.in_scale : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { in[1 + e] = m0[e] * p.in_scale; in[5 + e] = m1[e] * p.in_scale; }
+        in[9] = (PAD && x0 + 8 < p.Wd) ? row[x0 + 8] * p.in_scale : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < NK; ++kx) {
+          const float* w = ws + ((ky * NK + kx) * p.Cin + c) * 128 + oct * 8;
+          const f32x4 w0 = *(const f32x4*)w, w1 = *(const f32x4*)(w + 4);
+          const f32x2 wp[4] = {f32x2{w0[0], w0[1]}, f32x2{w0[2], w0[3]}, f32x2{w1[0], w1[1]}, f32x2{w1[2], w1[3]}};
+#pragma unroll
+          for (int px = 0; px < 8; ++px) {
+            const float iv = in[px + (TAPS == 9 ? kx : 1)];
+            const f32x2 ivv = f32x2{iv, iv};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[px][o] = __builtin_elementwise_fma(ivv, wp[o], acc[px][o]);
+          }
+        }
+      }
+    }
+    const int pix = y * p.Wd + x0;
+#pragma unroll
+    for (int px = 0; px < 8; ++px) {
+      float v[8];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        v[2 * o] = (acc[px][o][0] + bs[oct * 8 + 2 * o]) * p.out_scale;
+        v[2 * o + 1] = (acc[px][o][1] + bs[oct * 8 + 2 * o + 1]) * p.out_scale;
+      }
+      *(i32x4*)(p.y + (((size_t)b * HW + pix + px) * p.ldy + cb0 + oct * 8) * sizeof(T)) = pack8<T>(v);
+    }
   }
 }
 
@@ -316,6 +393,25 @@ extern "C" int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream)
   p.ldy = a->ldy; p.out_mode = a->out_mode; p.in_scale = a->in_scale; p.out_scale = a->out_scale;
   const long long pix = (long long)a->B * a->H * a->Wd;
   hipStream_t st = (hipStream_t)stream;
+  if (a->Wd % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_mode == DFW_OUT_T && a->Cout % 8 == 0 &&
+      a->taps * a->Cin <= 72 && (a->taps == 9 || a->taps == 1)) {
+    const size_t lds = ((size_t)a->taps * a->Cin + 1) * 128 * sizeof(float);
+    const long long cblocks = (a->Cout + 127) / 128, groups16 = (pix / 8 + 15) / 16;
+    long long iters = groups16 * cblocks / 2048;   // keep >= ~2048 workgroups in flight
+    iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+    p.iters = (int)iters;
+    dim3 grid((unsigned)((groups16 + iters - 1) / iters), (unsigned)cblocks);
+    const bool bf = a->dtype == DFW_BF16;
+    if (a->taps == 9) {
+      if (bf) hipLaunchKernelGGL((conv_small8w_kernel<__bf16, 9>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((conv_small8w_kernel<_Float16, 9>), grid, dim3(256), lds, st, p);
+    } else {
+      if (bf) hipLaunchKernelGGL((conv_small8w_kernel<__bf16, 1>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((conv_small8w_kernel<_Float16, 1>), grid, dim3(256), lds, st, p);
+    }
+    DFW_CHECK_LAUNCH();
+    return 0;
+  }
   if (a->Wd % 4 == 0 && ((uintptr_t)a->x % 16) == 0) {
     dim3 grid((unsigned)((pix / 4 + 255) / 256), (a->Cout + 7) / 8);
     if (a->dtype == DFW_BF16) hipLaunchKernelGGL((conv_small4_kernel<__bf16>), grid, dim3(256), 0, st, p);

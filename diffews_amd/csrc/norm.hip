@@ -12,6 +12,7 @@ namespace dfw {
 // part[b][chunk][g][2].
 struct GnP {
   const char* x; char* y; const float* gamma; const float* beta; float* part; float* mr;
+  float* coef;                                  // optional [B][C][2] (scale, shift) output of finalize
   int B, HW, C, groups, ldx, ldy, chunks, ppc;  // ppc = pixels per chunk
   float eps;
   int silu;
@@ -29,7 +30,20 @@ __global__ void gn_stats_kernel(const GnP p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
   const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
-  for (int px = p0 + slot; px < p1; px += slots) {
+  int px = p0 + slot;
+  for (; px + 3 * slots < p1; px += 4 * slots) {   // four loads in flight (same order of accumulation)
+    i32x4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *(const i32x4*)(xb + (size_t)(px + u * slots) * p.ldx * sizeof(T));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack8<T>(raw[u], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s[i] += f[i]; ss[i] += f[i] * f[i]; }
+    }
+  }
+  for (; px < p1; px += slots) {
     float f[8];
     unpack8<T>(*(const i32x4*)(xb + (size_t)px * p.ldx * sizeof(T)), f);
 #pragma unroll
@@ -56,7 +70,9 @@ __global__ void gn_stats_kernel(const GnP p) {
 }
 
 // Finalize: one wave per (image, group) folds the chunk partials in fp64 (lane-strided, then a fixed
-// butterfly) into mean / rstd: mr[b][g][2].
+// butterfly) into mean / rstd: mr[b][g][2]; with p.coef it also writes the per-channel affine
+// y = x*scale + shift (scale = rstd*gamma, shift = beta - mean*scale) that conv_halo.hip applies to
+// its input patch in LDS, so the normalised tensor never goes through HBM.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
   const int lane = threadIdx.x & 63;
   const int bg = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -80,6 +96,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
     if (var < 0.0) var = 0.0;
     p.mr[bg * 2 + 0] = (float)mean;
     p.mr[bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    a = mean;
+    a2 = 1.0 / sqrt(var + (double)p.eps);
+  }
+  if (p.coef) {
+    const float mean = (float)__shfl(a, 0, 64), rstd = (float)__shfl(a2, 0, 64);
+    const int cpg = p.C / p.groups;
+    for (int i = lane; i < cpg; i += 64) {
+      const int c = g * cpg + i;
+      const float sc = rstd * (p.gamma ? p.gamma[c] : 1.f);
+      const float sh = (p.beta ? p.beta[c] : 0.f) - mean * sc;
+      *(float2*)(p.coef + ((size_t)b * p.C + c) * 2) = make_float2(sc, sh);
+    }
   }
 }
 
@@ -102,7 +130,26 @@ __global__ void gn_apply_kernel(const GnP p) {
   }
   const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
   char* yb = p.y + ((size_t)b * p.HW * p.ldy + cc * 8) * sizeof(T);
-  for (int px = p0 + slot; px < p1; px += slots) {
+  // four independent 16-byte loads in flight per thread: one load per iteration left the kernel
+  // latency-bound at ~3.5 TB/s
+  int px = p0 + slot;
+  for (; px + 3 * slots < p1; px += 4 * slots) {
+    i32x4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load((const i32x4*)(xb + (size_t)(px + u * slots) * p.ldx * sizeof(T)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack8<T>(raw[u], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = f[i] * rs[i] + rh[i];
+        f[i] = p.silu ? silu_f(v) : v;
+      }
+      *(i32x4*)(yb + (size_t)(px + u * slots) * p.ldy * sizeof(T)) = pack8<T>(f);
+    }
+  }
+  for (; px < p1; px += slots) {
     float f[8];
     unpack8<T>(*(const i32x4*)(xb + (size_t)px * p.ldx * sizeof(T)), f);
 #pragma unroll
@@ -202,13 +249,15 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   int chunks, ppc, threads, slots;
   int rc = gn_geometry(a, chunks, ppc, threads, slots);
   if (rc) return rc;
-  if (!a->x || !a->y || !a->stats_ws) return DFW_EINVAL;
+  const bool coef_only = a->coef_out != nullptr;   // statistics -> per-channel affine, no apply pass
+  if (!a->stats_ws || (!coef_only && (!a->x || !a->y))) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   if (a->stats_ws_bytes < ((size_t)a->B * chunks * a->groups * 2 + (size_t)a->B * a->groups * 2) * sizeof(float))
     return DFW_EWORKSPACE;
   GnP p;
   p.x = (const char*)a->x; p.y = (char*)a->y; p.gamma = a->gamma; p.beta = a->beta;
   p.part = (float*)a->stats_ws;
+  p.coef = a->coef_out;
   p.mr = p.part + (size_t)a->B * chunks * a->groups * 2;
   p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.ldy = a->ldy;
   p.chunks = chunks; p.ppc = ppc; p.eps = a->eps; p.silu = a->silu;
@@ -218,6 +267,7 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   const dim3 gridf((a->B * a->groups + 3) / 4);
   dim3 grid(chunks, a->B);
   const bool pre = a->pre_partial != nullptr && a->pre_chunks > 0;
+  if (!pre && !a->x) return DFW_EINVAL;
   if (pre) {   // statistics were fused into the conv that produced x
     p.part = const_cast<float*>(a->pre_partial);
     p.chunks = a->pre_chunks;
@@ -229,13 +279,13 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, pa);
+    if (!coef_only) hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, pa);
   } else {
     if (!pre) hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, pa);
+    if (!coef_only) hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, pa);
   }
   DFW_CHECK_LAUNCH();
   return 0;

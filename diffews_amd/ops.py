@@ -125,12 +125,17 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
-            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0):
+            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
-    encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling."""
+    encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
+    gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x -- applied
+    inside the conv kernel where the library supports it for this shape, else by dfw_groupnorm first."""
     assert x.dim() == 4 and x.stride(3) == 1 and x.is_contiguous()
     B, Hi, Wi, Cin = x.shape
+    if gn_in is not None and not _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
+        x = groupnorm(x, *gn_in)
+        gn_in = None
     assert w.shape == (cout, 9 * Cin) and w.dtype == x.dtype and w.is_contiguous()
     if ups:
         assert stride == 1 and pad == 1
@@ -160,6 +165,9 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else L.OUT_T
     a.splitk = 0 if splitk is None else splitk
     a.batch, a.dtype = 1, _dt(x)
+    if gn_in is not None:
+        coef = groupnorm_coeff(x, *gn_in[:4])
+        a.gn_in_coef, a.gn_in_silu = coef.data_ptr(), int(gn_in[4])
     stats = None
     if gn_groups and not out_nchw_f32:
         # fused GroupNorm statistics of the output, when the planned kernel supports them
@@ -173,6 +181,20 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     if stats is not None:
         out._gn_stats = stats   # consumed by groupnorm(out, ...) -- valid while `out` is not modified
     return out
+
+
+def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
+    B, Hi, Wi, Cin = x.shape
+    if stride != 1 or pad != 1 or ups or out_nchw_f32 or splitk:
+        return False
+    a = L.GemmArgs()
+    a.A = a.W = a.C = x.data_ptr()
+    a.gn_in_coef = x.data_ptr()
+    a.a_elems, a.w_elems = x.numel(), w.numel()
+    a.M, a.N, a.K, a.lda, a.ldc = B * Hi * Wi, cout, 9 * Cin, Cin, cout
+    a.taps, a.Cin, a.Hi, a.Wi, a.Ho, a.Wo = 9, Cin, Hi, Wi, Hi, Wi
+    a.stride, a.pad, a.rows_per_img, a.out_scale, a.batch, a.dtype = 1, 1, Hi * Wi, 1.0, 1, _dt(x)
+    return L.lib().dfw_gemm_gn_input_ok(C.byref(a)) == 1
 
 
 def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None):
@@ -216,14 +238,25 @@ def cross_attention(q, k, v, heads, scale=None):
     return out
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu=False):
+def groupnorm_coeff(x, gamma, beta, groups, eps):
+    """GroupNorm statistics of x folded with gamma/beta into the per-(image, channel) affine
+    [B, C, 2] = (scale, shift) that conv3x3(gn_in=...) applies to its input inside the kernel."""
+    return groupnorm(x, gamma, beta, groups, eps, _coef_only=True)
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False):
     """GroupNorm (+SiLU) over NHWC x [B, H, W, C] (or [B, HW, C])."""
     assert x.is_contiguous()
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    y = torch.empty_like(x)
     a = L.GroupNormArgs()
-    a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
+    if _coef_only:
+        y = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
+        a.coef_out = y.data_ptr()
+        a.x, a.gamma, a.beta = x.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
+    else:
+        y = torch.empty_like(x)
+        a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
     a.B, a.HW, a.C, a.groups, a.ldx, a.ldy = B, HW, Cc, groups, Cc, Cc
     a.eps, a.silu, a.dtype = eps, int(silu), _dt(x)
     st = getattr(x, "_gn_stats", None)

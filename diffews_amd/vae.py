@@ -30,13 +30,14 @@ class _VaeResnet:
 
     def __call__(self, x):
         B, H, W, Cin = x.shape
-        h = ops.groupnorm(x, self.g1, self.b1, self.groups, 1e-6, silu=True)
-        h = ops.conv3x3(h, self.w1, self.cout, bias=self.cb1, gn_groups=self.groups)
-        h = ops.groupnorm(h, self.g2, self.b2, self.groups, 1e-6, silu=True)
+        # norm1/norm2 + SiLU ride inside the convs (normalised in LDS) where the shape allows it
+        h = ops.conv3x3(x, self.w1, self.cout, bias=self.cb1, gn_groups=self.groups,
+                        gn_in=(self.g1, self.b1, self.groups, 1e-6, True))
         sc = x
         if self.ws is not None:
             sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
-        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups)
+        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups,
+                           gn_in=(self.g2, self.b2, self.groups, 1e-6, True))
 
 
 class _VaeAttention:

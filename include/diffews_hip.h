@@ -78,6 +78,13 @@ typedef struct {
    * of the stored values, gn_partial[img][chunk][group][2] floats, chunk < dfw_gemm_gn_chunks().
    * Only kernels/shapes for which dfw_gemm_gn_chunks() returns > 0 support it. */
   float* gn_partial; int32_t gn_groups;
+  /* Optional fused GroupNorm(+SiLU) of the INPUT: when gn_in_coef != NULL the A operand is
+   * act(x*scale + shift) with (scale, shift) = gn_in_coef[img][cin][2] floats (written by
+   * dfw_groupnorm with coef_out set) and act = SiLU when gn_in_silu != 0; the kernel normalises its
+   * input patch in LDS, so resnet.norm1/norm2 + nonlinearity (diffusers ResnetBlock2D.forward, used at
+   * U:963-1012 and by the VAE) cost no HBM pass.  Only where dfw_gemm_gn_input_ok() returns 1;
+   * dfw_gemm fails with DFW_ESHAPE otherwise. */
+  const float* gn_in_coef; int32_t gn_in_silu;
 } dfw_gemm_args;
 
 int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);
@@ -88,6 +95,8 @@ int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n);
 /* Chunks per image of the fused GroupNorm partial sums this call would emit for gn_groups groups
  * (0: unsupported for this shape / kernel; run dfw_groupnorm's own statistics pass instead). */
 int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a);
+/* 1 when the kernel planned for these arguments can apply gn_in_coef to its input, else 0. */
+int32_t dfw_gemm_gn_input_ok(const dfw_gemm_args* a);
 
 /*
  * KV-fusion self-attention (the DiffewS-specific op): out = softmax(q [k_own ; k_bank]^T * scale) [v_own ; v_bank]
@@ -141,6 +150,10 @@ typedef struct {
   /* Optional: partial sums already produced by the conv that wrote x (dfw_gemm_args.gn_partial),
    * [B][pre_chunks][groups][2] floats; the statistics pass over x is then skipped. */
   const float* pre_partial; int32_t pre_chunks;
+  /* Optional: when coef_out != NULL only the statistics are reduced and the per-channel affine
+   * coef_out[B][C][2] = (rstd*gamma, beta - mean*rstd*gamma) is written; x is not normalised here
+   * (y may be NULL) -- the consumer conv applies it (dfw_gemm_args.gn_in_coef). */
+  float* coef_out;
 } dfw_groupnorm_args;
 
 int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream);
