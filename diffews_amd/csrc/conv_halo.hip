@@ -419,14 +419,16 @@ static bool halo_shape_ok(const GemmP& p, int& bn) {
   return (long long)(p.M / 256) * (p.N / bn) >= 192;
 }
 
-// GroupNorm-on-input fusion: worth it while the saved HBM pass (4 B per input element) outweighs the
-// in-LDS transform's VALU time, i.e. for the narrow high-resolution VAE levels.
+// GroupNorm-on-input fusion: which shapes the kernel supports.  Whether to USE it is the caller's
+// policy; measured on MI355X (scratch/bench_gnconv.py, norm + conv per call) it is not a win yet:
+// 256 -> 256 channels gains 4-9 % in isolation but the whole episode is 1 % slower with it, 128-channel
+// outputs lose 8 % (the BN=128 tile has one LDS fragment read per MFMA and is LDS-bound before the
+// transform is added), 128 -> 256 loses 30 % (36-step tiles: per-tile costs dominate), and at 512
+// input channels the saved HBM pass is only ~6 % of the conv.  The transform's exp + rcp per element
+// (2 quarter-rate ops x 1.27 halo factor) is what it has to get rid of -- see DESIGN.md.
 bool conv_halo_gn_input_ok(const GemmP& p) {
-  static const char* off = getenv("DFW_NO_GN_FUSE");
-  static const char* maxc = getenv("DFW_GN_FUSE_MAXC");
   int bn = 0;
-  if (off || !halo_shape_ok(p, bn)) return false;
-  return p.Cin <= (maxc ? atoi(maxc) : 256) && p.Cin <= 1024;
+  return halo_shape_ok(p, bn) && p.Cin <= 1024;
 }
 
 bool conv_halo_eligible(const GemmP& p, int& bn) {

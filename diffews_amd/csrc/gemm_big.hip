@@ -361,7 +361,7 @@ static int launch_big(const GemmP& p, hipStream_t st) {
   if (q.gn_chunks == 0) q.gn_partial = nullptr;
   q.tw = 0; q.tw_log2 = 0; q.tpr = 0; q.tpi = 0;
   if (p.taps == 9) {
-    q.tw = 16; q.tw_log2 = getenv("DFW_HACK_SKIPA") ? 99 : 4;   // 99: timing experiment, A tiles read as zeros
+    q.tw = 16; q.tw_log2 = 4;
     q.tpr = p.Wo / 16;
     q.tpi = q.tpr * (p.Ho / (BM / 16));
   }

@@ -5,6 +5,7 @@ Every function launches hand-written gfx950 kernels from libdiffews_hip.so on
 (`[B, H, W, C]` or `[rows, C]`) in the engine storage dtype (bf16 or fp16).
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -125,15 +126,19 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
-            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None):
+            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, fuse_gn_in=None):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
     gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x -- applied
-    inside the conv kernel where the library supports it for this shape, else by dfw_groupnorm first."""
+    by dfw_groupnorm first, or (fuse_gn_in=True, or DFW_GN_FUSE=1 in the environment) inside the conv
+    kernel where the library supports that for the shape.  The fused form is off by default: measured
+    on MI355X it does not pay yet (conv_halo.hip)."""
     assert x.dim() == 4 and x.stride(3) == 1 and x.is_contiguous()
     B, Hi, Wi, Cin = x.shape
-    if gn_in is not None and not _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
+    if fuse_gn_in is None:
+        fuse_gn_in = _GN_FUSE_DEFAULT
+    if gn_in is not None and not (fuse_gn_in and _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk)):
         x = groupnorm(x, *gn_in)
         gn_in = None
     assert w.shape == (cout, 9 * Cin) and w.dtype == x.dtype and w.is_contiguous()
@@ -181,6 +186,9 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     if stats is not None:
         out._gn_stats = stats   # consumed by groupnorm(out, ...) -- valid while `out` is not modified
     return out
+
+
+_GN_FUSE_DEFAULT = os.environ.get("DFW_GN_FUSE", "0") == "1"
 
 
 def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):

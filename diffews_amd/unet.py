@@ -298,13 +298,17 @@ class MyUNet2DConditionModel:
             raise ValueError("latent size must be divisible by 8")
         # ---- 1. time (U:991-1015)
         c0 = cfg["block_out_channels"][0]
-        tproj = self._time_proj(B, timestep)  # [B, sum Cout] fp32: all 22 time_emb_proj outputs
-        # ---- prompt tokens
-        ehs = encoder_hidden_states.to(device=dev, dtype=dt)
-        if ehs.shape[0] != B:
-            raise ValueError("encoder_hidden_states batch must match sample batch")
-        L_ctx = ehs.shape[1]
-        ehs2d = ehs.reshape(B * L_ctx, ehs.shape[2]).contiguous()
+        kv_all = None
+        if encoder_hidden_states is None:     # folded conditioning (fold_conditioning)
+            tproj, ehs2d, kv_all, L_ctx = self._folded_rows(B, timestep)
+        else:
+            tproj = self._time_proj(B, timestep)  # [B, sum Cout] fp32: all 22 time_emb_proj outputs
+            # ---- prompt tokens
+            ehs = encoder_hidden_states.to(device=dev, dtype=dt)
+            if ehs.shape[0] != B:
+                raise ValueError("encoder_hidden_states batch must match sample batch")
+            L_ctx = ehs.shape[1]
+            ehs2d = ehs.reshape(B * L_ctx, ehs.shape[2]).contiguous()
         # ---- 2. conv_in | conv_in_ref (U:1117-1121)
         if is_target:
             if Cin != cfg["in_channels"]:
@@ -314,7 +318,7 @@ class MyUNet2DConditionModel:
             if Cin != cfg["in_channels_ref"]:
                 raise ValueError(f"support pass expects {cfg['in_channels_ref']} channels, got {Cin}")
             x = ops.conv_small(x_in, self.w_in_ref, self.b_in_ref, c0, 9, dt)
-        out = self._trunk(x, tproj, ehs2d, L_ctx, 0, out_scale)
+        out = self._trunk(x, tproj, ehs2d, L_ctx, 0, out_scale, kv_all)
         if in_dtype in (torch.float16, torch.bfloat16, torch.float64):
             out = out.to(in_dtype)
         if not return_dict:
@@ -334,8 +338,42 @@ class MyUNet2DConditionModel:
         semb = ops.linear(e, self.te_w2, bias=self.te_b2, act=L.ACT_SILU)
         return ops.linear(semb, self.tp_w, bias=self.tp_b, out_f32=True)
 
+    # ------------------------------------------------------------------ constant folding
     @torch.no_grad()
-    def forward_pair(self, ref_sample, query_sample, timestep, ehs_ref, ehs_query, out_scale=1.0):
+    def fold_conditioning(self, timestep, prompt_embed):
+        """The prompt ("" through CLIP, P:585-601) and the single timestep (S:107-180 -> [1]) are
+        constants of a checkpoint, hence so are the timestep embedding (U:991-1015), all 22 resnet
+        time_emb_proj outputs and all 16 attn2 K/V projections.  Compute them ONCE here; forwards
+        called with encoder_hidden_states=None (and the same timestep) then start at conv_in with no
+        conditioning kernels at all.  prompt_embed: [1, L, cross_attention_dim] or [L, D]."""
+        dt, dev = self.dtype, self.device
+        pe = prompt_embed.to(device=dev, dtype=dt)
+        pe = pe.reshape(-1, pe.shape[-1]).contiguous()
+        t = float(timestep)
+        self._folded = {"t": t, "L": pe.shape[0], "prompt": pe, "tproj": self._time_proj(1, t),
+                        "kv": ops.linear(pe, self.kv_w_all), "rows": {}}
+        return self
+
+    def unfold_conditioning(self):
+        self._folded = None
+
+    def _folded_rows(self, B, timestep):
+        f = getattr(self, "_folded", None)
+        if f is None:
+            raise ValueError("encoder_hidden_states=None needs fold_conditioning() first")
+        if torch.is_tensor(timestep):
+            if timestep.device.type != "cpu" or timestep.numel() != 1:
+                raise ValueError("folded conditioning takes the timestep as a python number or a CPU scalar")
+        if float(timestep) != f["t"]:
+            raise ValueError(f"conditioning was folded for timestep {f['t']}, got {float(timestep)}")
+        if B not in f["rows"]:   # materialised once per batch size (rowbias / K/V rows are per image)
+            f["rows"][B] = (f["tproj"].expand(B, -1).contiguous(), f["prompt"].repeat(B, 1).contiguous(),
+                            f["kv"].repeat(B, 1).contiguous())
+        tproj, ehs2d, kv = f["rows"][B]
+        return tproj, ehs2d, kv, f["L"]
+
+    @torch.no_grad()
+    def forward_pair(self, ref_sample, query_sample, timestep, ehs_ref=None, ehs_query=None, out_scale=1.0):
         """Support and query passes in layer lock-step: ONE trunk pass over the batch
         [support images ; query images] (weights read once, twice the rows per GEMM).  Per image the
         arithmetic is that of forward(ref, is_target=False) followed by forward(query): every op on
@@ -349,19 +387,23 @@ class MyUNet2DConditionModel:
         if zr.shape[1] != cfg["in_channels_ref"] or zq.shape[1] != cfg["in_channels"]:
             raise ValueError("forward_pair expects (in_channels_ref, in_channels) channel counts")
         c0 = cfg["block_out_channels"][0]
-        tproj = self._time_proj(n_ref + bq, timestep)
-        ehs = torch.cat([ehs_ref.to(device=dev, dtype=dt), ehs_query.to(device=dev, dtype=dt)], dim=0)
-        L_ctx = ehs.shape[1]
-        ehs2d = ehs.reshape((n_ref + bq) * L_ctx, ehs.shape[2]).contiguous()
+        kv_all = None
+        if ehs_ref is None and ehs_query is None:
+            tproj, ehs2d, kv_all, L_ctx = self._folded_rows(n_ref + bq, timestep)
+        else:
+            tproj = self._time_proj(n_ref + bq, timestep)
+            ehs = torch.cat([ehs_ref.to(device=dev, dtype=dt), ehs_query.to(device=dev, dtype=dt)], dim=0)
+            L_ctx = ehs.shape[1]
+            ehs2d = ehs.reshape((n_ref + bq) * L_ctx, ehs.shape[2]).contiguous()
         x = torch.empty(n_ref + bq, zq.shape[2], zq.shape[3], c0, dtype=dt, device=dev)
         x[:n_ref] = ops.conv_small(zr, self.w_in_ref, self.b_in_ref, c0, 9, dt)
         x[n_ref:] = ops.conv_small(zq, self.w_in, self.b_in, c0, 9, dt)
-        out = self._trunk(x, tproj, ehs2d, L_ctx, n_ref, out_scale)
+        out = self._trunk(x, tproj, ehs2d, L_ctx, n_ref, out_scale, kv_all)
         return out[n_ref:]
 
-    def _trunk(self, x, tproj, ehs2d, L_ctx, n_ref, out_scale):
+    def _trunk(self, x, tproj, ehs2d, L_ctx, n_ref, out_scale, kv_all=None):
         # all layers' prompt K/V in one launch: [B*L, sum(2C)]; layers take column slices
-        ehs2d = (ehs2d, ops.linear(ehs2d, self.kv_w_all))
+        ehs2d = (ehs2d, kv_all if kv_all is not None else ops.linear(ehs2d, self.kv_w_all))
         # ---- 3. down (U:1153-1175)
         skips = [x]
         for blk in self.down:

@@ -118,6 +118,48 @@ def test_lockstep_pair_equals_two_passes(models):
         assert rel(pair, ref) < TOL_Z0[dt], (b, s)
 
 
+def test_folded_conditioning(models):
+    """prompt + timestep folded at load (time projections and all attn2 K/V precomputed
+    once) == passing encoder_hidden_states / timestep every call; wrong timestep or no fold raise."""
+    unet, te, dt, pipe = models["unet"], models["te"], models["dt"], models["pipe"]
+    g = torch.Generator().manual_seed(9)
+    b, s = 2, 2
+    zr = (torch.randn(b * s, 8, 16, 16, generator=g) * 0.5).cuda()
+    zq = (torch.randn(b, 4, 16, 16, generator=g) * 0.5).cuda()
+    ehs, ehs_r = te.repeat(b, 1, 1).cuda(), te.repeat(b * s, 1, 1).cuda()
+    unet.unfold_conditioning()
+    with pytest.raises(ValueError):
+        unet(zq, 1, None)
+    plain_pair = unet.forward_pair(zr, zq, 1, ehs_r, ehs)
+    unet.clear_attn_bank()
+    unet(zr, 1, ehs_r, is_target=False)
+    plain_q = unet(zq, 1, ehs).sample
+    unet.clear_attn_bank()
+    unet.fold_conditioning(1, te)
+    with pytest.raises(ValueError):
+        unet(zq, 2, None)
+    fold_pair = unet.forward_pair(zr, zq, torch.tensor(1))
+    unet(zr, 1, None, is_target=False)
+    fold_q = unet(zq, 1, None).sample
+    unet.clear_attn_bank()
+    # same kernels on the same values; only the row count of the conditioning GEMMs (1 vs B) differs
+    assert rel(fold_pair, plain_pair) < 2e-3 and rel(fold_q, plain_q) < 2e-3
+    # pipeline: run_episodes folds by default
+    sup, qry, msk = _episode(2, 1, 64, seed=4)
+    pipe.fold_conditioning = False
+    a = pipe.run_episodes(sup, qry, msk)["z0"]
+    pipe.fold_conditioning = True
+    pipe._fold_key = None
+    c = pipe.run_episodes(sup, qry, msk)["z0"]
+    assert pipe._fold_key is not None and rel(c, a) < 2e-3
+    pipe.test_timestep = 3          # E:373 sets this attribute after construction: must re-fold
+    d = pipe.run_episodes(sup, qry, msk)["z0"]
+    pipe.fold_conditioning = False
+    e = pipe.run_episodes(sup, qry, msk)["z0"]
+    pipe.test_timestep, pipe.fold_conditioning = 1, True
+    assert rel(d, e) < 2e-3 and rel(d, a) > 1e-3
+
+
 def test_bank_semantics(models):
     """(i) a pass right after clear_attn_bank is plain self-attention whatever ran before;
     (ii) forgetting to clear turns the next pass into a read pass (reference behaviour, A:251-258)."""

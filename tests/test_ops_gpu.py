@@ -160,7 +160,7 @@ def test_conv_fused_groupnorm_input(ops, dtype, silu, B, H, W, Cin, Cout):
     g, b = (torch.randn(Cin) * 0.2 + 1).cuda(), (torch.randn(Cin) * 0.2).cuda()
     g2, b2 = (torch.randn(Cout) * 0.2 + 1).cuda(), (torch.randn(Cout) * 0.2).cuda()
     assert ops._gn_input_fusable(x, w, Cout, 1, 1, False, False, None), "fusion expected for this shape"
-    fused = ops.conv3x3(x, w, Cout, bias=bias, residual=res, gn_groups=32, gn_in=(g, b, 32, 1e-6, silu))
+    fused = ops.conv3x3(x, w, Cout, bias=bias, residual=res, gn_groups=32, gn_in=(g, b, 32, 1e-6, silu), fuse_gn_in=True)
     xn = ops.groupnorm(x, g, b, 32, 1e-6, silu=silu)
     plain = ops.conv3x3(xn, w, Cout, bias=bias, residual=res)
     ref = F.conv2d(xn.float().permute(0, 3, 1, 2), unpack3x3(w, Cin), bias, padding=1).permute(0, 2, 3, 1) + res.float()
