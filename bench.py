@@ -248,12 +248,13 @@ def main():
         n_gpus = world
         eps = n_gpus * b * args.steps / elapsed
         line = {
-            "metric": "few-shot episodes/sec (512x512, 1-shot, SD-2 UNet)", "value": round(eps, 3),
+            "metric": f"few-shot episodes/sec ({res}x{res}, {s}-shot, SD-2 UNet)", "value": round(eps, 3),
             "unit": "episodes/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SD-2.1 UNet + SD VAE, {res}x{res}, {s}-shot, {b} episodes/GPU/step "
-                                   f"(BASELINE.json configs[1]){' TINY-DEBUG' if args.tiny else ''}",
+                                   f"({'BASELINE.json configs[1]' if (res, s, b) == (512, 1, 4) else 'non-default configuration'})"
+                                   f"{' TINY-DEBUG' if args.tiny else ''}",
                        "episodes_per_gpu_per_step": b, "nshot": s, "resolution": res,
                        "parallelism": f"episode-sharded x{n_gpus}", "hip_graph": graph is not None},
             "roofline": roof, "cpu_baseline": cpu,

@@ -60,6 +60,12 @@ class ConvSmallArgs(C.Structure):
                 ("in_scale", _f32), ("out_scale", _f32), ("out_mode", _i32), ("dtype", _i32)]
 
 
+class ImageArgs(C.Structure):
+    _fields_ = [("src", _vp), ("H", _i32), ("W", _i32), ("out_h", _i32), ("out_w", _i32),
+                ("xbounds", _vp), ("xcoef", _vp), ("xk", _i32), ("ybounds", _vp), ("ycoef", _vp), ("yk", _i32),
+                ("tmp", _vp), ("dst", _vp), ("lut", _vp)]
+
+
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dfw_version": (_i32, []),
@@ -80,6 +86,10 @@ SYMBOLS = {
     "dfw_concat_channels": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dfw_timestep_embedding": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_seg_postprocess": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "dfw_resample_ksize": (_i32, [_i32, _i32]),
+    "dfw_resample_coeffs": (_i32, [_i32, _i32, _vp, _vp]),
+    "dfw_image_to_tensor": (_i32, [C.POINTER(ImageArgs), _vp]),
+    "dfw_mask_to_tensor": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
         iy >>= ush;
         ix >>= ush;
         const uint32_t off = ((a_pix[i] + (uint32_t)(iy * p.Wi + ix)) * (uint32_t)p.lda + coff) * (uint32_t)sizeof(T);
-        dma16(ra, (ok && p.tw_log2 != 99) ? off : kOOB, dst + i * 8192);
+        dma16(ra, ok ? off : kOOB, dst + i * 8192);
       }
       if (++cc == cpt) { cc = 0; ++tap; }
     }

@@ -19,12 +19,28 @@ def episode_batches(indices, batch):
 
 @torch.no_grad()
 def test_diffusion(pipe, n_episodes, nshot=1, res=512, batch=1, benchmark="coco", fold=0, r_threshold=0.25,
-                   rank=0, world_size=1, make_batch=None, device=None):
-    """Run `n_episodes` synthetic episodes sharded over `world_size` ranks; returns (miou, fb_iou, meter).
-    `make_batch(indices)` may supply real episodes (same dict as episodes.make_episode_batch + 'class_id')."""
+                   rank=0, world_size=1, make_batch=None, device=None, episodes=None):
+    """Run `n_episodes` episodes sharded over `world_size` ranks; returns (miou, fb_iou, meter).
+    Sources, first match wins:
+      episodes   -- indexable of HOST episodes (decoded PIL images / uint8 arrays + class-id masks, the
+                    material of DatasetCOCO.load_frame, coco.py:77-107): this rank's share goes through the
+                    GPU input pipeline (input_pipeline.EpisodeLoader: resize / normalise / mask kernels on a
+                    side stream, prefetched);
+      make_batch -- make_batch(indices) returns device tensors (dict of episodes.make_episode_batch + 'class_id');
+      otherwise  -- synthetic episodes (episodes.make_episode_batch)."""
     device = device or pipe.device
     meter = AverageMeter(benchmark, fold_class_ids(benchmark, fold), device=device)
     mine = ep.shard(n_episodes, rank, world_size)
+    if episodes is not None:
+        from .input_pipeline import EpisodeLoader
+        loader = EpisodeLoader((episodes[i] for i in mine), res, batch, nshot, device=device)
+        for bt in loader:
+            r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"],
+                                  r_threshold=r_threshold)
+            meter.update_from_counts(r["counts"], bt["class_id"].to(device))
+        meter.all_reduce()
+        miou, fb_iou, _ = meter.compute_iou()
+        return float(miou), float(fb_iou), meter
     for idx in episode_batches(mine, batch):
         if make_batch is not None:
             bt = make_batch(idx)

@@ -218,6 +218,36 @@ int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_t* gt, int6
                         uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
                         dfw_stream_t stream);
 
+/*
+ * Episode input transform (evaluation_util/data/dataset.py:36-40: Resize((S,S)) on the PIL image,
+ * ToTensor, Normalize([0.5],[0.5]); coco.py:36-46: nearest resize of the class mask;
+ * main_oss.py:100: mask -> 3 channels, {0,1} -> {-1,+1}).  Bit-exact with Pillow's ImagingResample
+ * (BILINEAR, 8 bits per channel: horizontal then vertical pass, uint8 intermediate, 22-bit fixed-point
+ * weights) and ATen's `nearest`.  JPEG/PNG decoding stays with the caller.
+ *
+ * dfw_resample_ksize / dfw_resample_coeffs are HOST functions: Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc for one axis; bounds [out_size][2] = (first input index, tap count),
+ * coeffs [out_size][ksize].  The caller copies them to the device next to the image bytes.
+ */
+int32_t dfw_resample_ksize(int32_t in_size, int32_t out_size);
+int dfw_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coeffs);
+
+typedef struct {
+  const uint8_t* src;                 /* device, [H][W][3] RGB bytes */
+  int32_t H, W, out_h, out_w;
+  const int32_t* xbounds; const int32_t* xcoef; int32_t xk;   /* device, from dfw_resample_coeffs(W, out_w) */
+  const int32_t* ybounds; const int32_t* ycoef; int32_t yk;   /* device, from dfw_resample_coeffs(H, out_h) */
+  uint8_t* tmp;                       /* device scratch, [H][out_w][3] */
+  float* dst;                         /* device, [3][out_h][out_w] fp32 */
+  const float* lut;                   /* device, 256 floats: byte v after ToTensor + Normalize */
+} dfw_image_args;
+
+int dfw_image_to_tensor(const dfw_image_args* a, dfw_stream_t stream);
+/* mask: device [H][W] class ids (elem_bytes 1 = uint8 PNG, 4 = int32); on = (id == class_value);
+ * dst_pm1 [3][out_h][out_w] fp32 in (-1,+1) and/or dst_bin [out_h][out_w] uint8 in (0,1). */
+int dfw_mask_to_tensor(const void* mask, int32_t elem_bytes, int32_t H, int32_t W, int32_t class_value,
+                       int32_t out_h, int32_t out_w, float* dst_pm1, uint8_t* dst_bin, dfw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
