@@ -32,7 +32,7 @@ class FsaArgs(C.Structure):
                 ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32), ("n_bank", _i32), ("nshot", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldkb", _i32), ("ldvb", _i32), ("ldo", _i32),
                 ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("kb_bs", _i64), ("vb_bs", _i64), ("o_bs", _i64),
-                ("scale", _f32), ("dtype", _i32)]
+                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32)]
 
 
 class XattnArgs(C.Structure):

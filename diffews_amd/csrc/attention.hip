@@ -23,7 +23,7 @@ namespace dfw {
 struct FsaP {
   const char* q; const char* k; const char* v; const char* kb; const char* vb; char* out;
   uint32_t q_bytes, k_bytes, v_bytes, kb_bytes, vb_bytes;
-  int batch, heads, n_q, n_kv, n_bank, nshot;
+  int batch, heads, n_q, n_kv, n_bank, nshot, n_plain;
   int ldq, ldk, ldv, ldkb, ldvb, ldo;
   long long q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs;
   float c;  // scale * log2(e)
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   // in one instruction stream, so one block's softmax VALU work overlaps the other's MFMAs, and
   // every K / V fragment read from LDS feeds two MFMAs.
   constexpr int KT = 64, S = 4;
+  constexpr float kDefer = 8.0f;            // see the online softmax below
   constexpr int TILE = KT * 128;            // bytes of one K (or V) tile
   constexpr int STAGE = 2 * TILE;
   constexpr int DPS = 16 / NW;              // DMA wave-instructions per stage per wave (K + V)
@@ -295,7 +296,11 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // Longest work first: images [n_plain, batch) also walk their episode's bank (the query images of a
+  // lock-step [support ; query] launch) and sit at the END of the batch, so the z walk is reversed --
+  // their workgroups are dispatched first and the short support-image ones fill in behind them.
+  const int head = blockIdx.y, b = (int)gridDim.z - 1 - (int)blockIdx.z;
+  const int bank_b = b - p.n_plain;          // episode index into the bank (< 0: own keys only)
   const int q0 = blockIdx.x * (NW * 32 * QB) + wave * (32 * QB);
   const uint32_t lds0 = lds_addr(smem);
 
@@ -318,15 +323,15 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   // lane -> row + (lane>>3), LDS slot lane&7; source chunk = slot ^ swizzle(row)
   const int lrow = lane >> 3, slot = lane & 7;
   const int tiles_own = (p.n_kv + KT - 1) / KT;
-  const int tiles_bank = p.nshot > 0 ? (p.n_bank + KT - 1) / KT : 0;
-  const int ntiles = tiles_own + p.nshot * tiles_bank;
+  const int tiles_bank = (p.nshot > 0 && bank_b >= 0) ? (p.n_bank + KT - 1) / KT : 0;
+  const int ntiles = tiles_own + (tiles_bank ? p.nshot * tiles_bank : 0);
   int ld_seg = 0, ld_tt = 0;   // segment / tile-in-segment of the next tile to load
   auto issue = [&](int st) {
     const uint32_t dst = lds0 + (uint32_t)st * STAGE;
     const int key0 = ld_tt * KT;
     const bool own = ld_seg == 0;
     const int nseg = own ? p.n_kv : p.n_bank;
-    const size_t img = own ? (size_t)b : (size_t)b * p.nshot + (ld_seg - 1);
+    const size_t img = own ? (size_t)b : (size_t)bank_b * p.nshot + (ld_seg - 1);
     const size_t kbase = img * (own ? p.k_bs : p.kb_bs) + head * 64;
     const size_t vbase = img * (own ? p.v_bs : p.vb_bs) + head * 64;
     const int ldk = own ? p.ldk : p.ldkb, ldv = own ? p.ldv : p.ldvb;
@@ -352,13 +357,20 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
     if (++ld_tt == lim) { ld_tt = 0; ++ld_seg; }
   };
 
-  uint32_t kr[2];
+  // LDS fragment addresses as (lane-constant base) + (compile-time immediate): the swizzles depend on
+  // the row only through bits that the +32 (K block), +16 / +8 (V^T row groups) steps leave unchanged,
+  // so 4 K bases and 2 V bases replace 8 + 16 per-fragment address registers (which spilled at the
+  // 128-VGPR budget of 4 waves per SIMD, and cost a v_or each per tile).
+  uint32_t kq[4];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int row = kb * 32 + lr;
-    kr[kb] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
-  }
+  for (int ss = 0; ss < 4; ++ss) kq[ss] = (uint32_t)(lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4)) ^ (uint32_t)(ss << 5);
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  uint32_t vq[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int dcol = d * 32 + 16 * tg + 4 * tp, row0 = 4 * lh + tq;
+    vq[d] = (uint32_t)(row0 * 128 + (((dcol >> 3) ^ (((row0 >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1));
+  }
 
   f32x16 o[QB][2];
   float m_run[QB], l_run[QB];
@@ -376,6 +388,11 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
 #pragma unroll
   for (int i = 0; i < S - 1; ++i)
     if (issued < ntiles) { issue(i); ++issued; }
+  // The Q fragments were fetched with compiler-visible buffer loads; without an explicit wait the
+  // compiler cannot prove them complete across the loop back-edge and plants vmcnt(5..2) in front of
+  // every tile's QK^T MFMAs -- which also drains the hand-counted K/V DMA ring early.  One full wait
+  // here (the first tiles are needed by the first iteration anyway) removes them from the loop.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   int c_tt = 0, c_own = 1;  // compute-side tile-in-segment / own-segment flag
   for (int t = 0; t < ntiles; ++t) {
     const int younger = issued - t - 1;
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
-        typename Tr<T>::v8 kf = as_v8<T>(*(const i32x4*)(kbuf + (kr[kb] ^ (ss << 5))));
+        typename Tr<T>::v8 kf = as_v8<T>(*(const i32x4*)(kbuf + kq[ss] + kb * 4096));
 #pragma unroll
         for (int g = 0; g < QB; ++g) s[g][kb] = Tr<T>::mfma(kf, qf[g][ss], s[g][kb]);
       }
@@ -425,10 +442,23 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[g][kb][r]);
       mt = half_swap_max(mt);
-      const float m_new = fmaxf(m_run[g], mt);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[g] - m_new) * p.c);
-      const float mc = m_new * p.c;
-      m_run[g] = m_new;
+      // Deferred rescale: O and l keep their reference maximum m_run until some row's maximum has
+      // grown by more than kDefer (log2 units), so the O-wide multiply runs on a few tiles instead of
+      // every tile; until then this tile's P is simply bounded by 2^kDefer instead of 1 (exact in
+      // fp32 sums, same relative rounding in the 16-bit P).  The decision is taken BEFORE this tile's
+      // P is exponentiated and after the previous tile's P.V completed, so O, l and P always share
+      // one scale.  Wave-uniform branch (ballot): every lane then moves to its own true maximum.
+      if (__builtin_amdgcn_ballot_w64((mt - m_run[g]) * p.c > kDefer) != 0) {
+        const float m_new = fmaxf(m_run[g], mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[g] - m_new) * p.c);
+        m_run[g] = m_new;
+        l_run[g] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha;
+      }
+      const float mc = m_run[g] * p.c;
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -438,11 +468,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
           s[g][kb][r] = e;
           psum += e;
         }
-      l_run[g] = l_run[g] * alpha + psum;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha;
+      l_run[g] += psum;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -456,15 +482,12 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
-        const int keybase = kb * 32 + 16 * t2 + 4 * lh;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const int dcol = d * 32 + 16 * tg + 4 * tp;
-          const int row0 = keybase + tq, row1 = row0 + 8;
-          const uint32_t a0 = row0 * 128 + ((((dcol >> 3) ^ (((row0 >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1);
-          const uint32_t a1 = row1 * 128 + ((((dcol >> 3) ^ (((row1 >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1);
-          typename Tr<T>::v4 lo = lds_tr_read<T>(vbuf + a0);
-          typename Tr<T>::v4 hi = lds_tr_read<T>(vbuf + a1);
+          // rows (kb*32 + 16*t2 + 4*lh + tq) and +8 of the V tile
+          const char* vd = vbuf + vq[d] + (kb * 32 + 16 * t2) * 128;
+          typename Tr<T>::v4 lo = lds_tr_read<T>(vd);
+          typename Tr<T>::v4 hi = lds_tr_read<T>(vd + 8 * 128);
           typename Tr<T>::v8 vf;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
@@ -565,6 +588,7 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->out) return DFW_EINVAL;
   if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kv <= 0 || a->nshot < 0) return DFW_EINVAL;
   if (a->nshot > 0 && (!a->k_bank || !a->v_bank || a->n_bank <= 0)) return DFW_EINVAL;
+  if (a->n_plain < 0 || a->n_plain > a->batch || (a->n_plain > 0 && a->nshot == 0)) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8 != 0) return DFW_ESHAPE;
   if (a->nshot > 0 && (a->ldkb | a->ldvb) % 8 != 0) return DFW_ESHAPE;
@@ -577,22 +601,25 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   const int64_t ve = extent(a->batch, a->v_bs, a->n_kv, a->ldv, a->heads);
   int64_t kbe = 0, vbe = 0;
   if (a->nshot > 0) {
-    kbe = extent(a->batch * a->nshot, a->kb_bs, a->n_bank, a->ldkb, a->heads);
-    vbe = extent(a->batch * a->nshot, a->vb_bs, a->n_bank, a->ldvb, a->heads);
+    const int nb = (a->batch - a->n_plain) * a->nshot;   // bank images
+    if (nb > 0) {
+      kbe = extent(nb, a->kb_bs, a->n_bank, a->ldkb, a->heads);
+      vbe = extent(nb, a->vb_bs, a->n_bank, a->ldvb, a->heads);
+    }
   }
   const int64_t lim = (1ll << 30);  // elements (2 bytes each)
   if (qe >= lim || ke >= lim || ve >= lim || kbe >= lim || vbe >= lim) return DFW_ERANGE;
   p.q_bytes = (uint32_t)(qe * 2); p.k_bytes = (uint32_t)(ke * 2); p.v_bytes = (uint32_t)(ve * 2);
   p.kb_bytes = (uint32_t)(kbe * 2); p.vb_bytes = (uint32_t)(vbe * 2);
   p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_kv = a->n_kv;
-  p.n_bank = a->n_bank; p.nshot = a->nshot;
+  p.n_bank = a->n_bank; p.nshot = a->nshot; p.n_plain = a->n_plain;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldkb = a->ldkb; p.ldvb = a->ldvb; p.ldo = a->ldo;
   p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.kb_bs = a->kb_bs; p.vb_bs = a->vb_bs; p.o_bs = a->o_bs;
   p.c = a->scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   static const char* v1 = getenv("DFW_FSA_V1");
   const bool bf = a->dtype == DFW_BF16;
-  if (v1) {
+  if (v1 && a->n_plain == 0) {
     dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
     if (bf) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);

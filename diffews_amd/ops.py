@@ -205,9 +205,10 @@ def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
     return L.lib().dfw_gemm_gn_input_ok(C.byref(a)) == 1
 
 
-def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None):
+def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None, n_plain=0):
     """KV-fusion self-attention.  q/k/v: [B, N, heads*64] views (token stride = stride(1));
-    k_bank/v_bank: [B*nshot, Nb, heads*64] views written by the support pass."""
+    k_bank/v_bank: [(B-n_plain)*nshot, Nb, heads*64] views written by the support pass.
+    n_plain: the first n_plain batch entries ignore the bank (lock-step [support ; query] launch)."""
     B, N, Cq = q.shape
     assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
@@ -219,13 +220,13 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), Cq
     a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     if nshot:
-        assert k_bank.shape[0] == B * nshot and k_bank.stride(2) == 1 and v_bank.stride(2) == 1
+        assert k_bank.shape[0] == (B - n_plain) * nshot and k_bank.stride(2) == 1 and v_bank.stride(2) == 1
         assert k_bank.dtype == q.dtype and v_bank.shape == k_bank.shape
         a.k_bank, a.v_bank = k_bank.data_ptr(), v_bank.data_ptr()
         a.n_bank, a.nshot = k_bank.shape[1], nshot
         a.ldkb, a.ldvb, a.kb_bs, a.vb_bs = k_bank.stride(1), v_bank.stride(1), k_bank.stride(0), v_bank.stride(0)
     a.scale = scale if scale is not None else 64 ** -0.5
-    a.dtype = _dt(q)
+    a.dtype, a.n_plain = _dt(q), n_plain
     L.check(L.lib().dfw_fsa_attention(C.byref(a), _stream()), "dfw_fsa_attention")
     return out
 

@@ -110,10 +110,9 @@ class _Transformer:
             bq = B - n_ref
             if bq <= 0 or n_ref % bq != 0:
                 raise ValueError(f"{n_ref} support images is not a multiple of the {bq} query images")
-            att = torch.empty(B, N, C, dtype=x.dtype, device=x.device)
-            ops.fsa_attention(q[:n_ref], k[:n_ref], v[:n_ref], heads, out=att[:n_ref])
-            ops.fsa_attention(q[n_ref:], k[n_ref:], v[n_ref:], heads, k[:n_ref], v[:n_ref], nshot=n_ref // bq,
-                              out=att[n_ref:])
+            # one launch for both passes: support images attend over their own keys, query images over
+            # [own ; their episode's support images]; long (query) workgroups are dispatched first
+            att = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=n_ref // bq, n_plain=n_ref)
         elif self.k_bank is None:  # A:251-252 / 260-261: first pass after clear fills the bank
             self.k_bank, self.v_bank = k, v
             att = ops.fsa_attention(q, k, v, heads)

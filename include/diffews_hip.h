@@ -115,6 +115,11 @@ typedef struct {
   int64_t q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs; /* element strides between batch items */
   float scale;
   int32_t dtype;
+  /* Lock-step launch over [support images ; query images] (one trunk pass for both UNet passes): the
+   * first n_plain batch entries attend over their own keys only (the bank-fill pass, A:251-252); entry
+   * b >= n_plain is episode b - n_plain and reads bank images (b - n_plain)*nshot + shot.  0 = every
+   * entry reads the bank (the two-pass form). */
+  int32_t n_plain;
 } dfw_fsa_args;
 
 int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream);

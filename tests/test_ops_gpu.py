@@ -246,6 +246,59 @@ def test_fsa_attention_online_softmax_rescale(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("step", [0.5, 2.0, 5.0, 12.0])
+def test_fsa_attention_deferred_rescale_ramp(ops, dtype, step):
+    """The kernel rescales O / l only when a row's maximum grew by more than 2^8 since the last rescale
+    (deferred rescale).  A bounded random test never takes either side deliberately, so build rows whose
+    score maximum climbs by `step` log2-units per 64-key tile over 16 tiles: 0.5 never fires after the
+    first tile (P up to 2^8 at the old scale), 2.0 fires every 5th tile, 5.0 every 2nd, 12.0 every tile --
+    and per row, every element must still match (a mis-ordered rescale corrupts only the rows that grew)."""
+    B, heads, N, C = 1, 1, 1024, 64
+    g = torch.Generator().manual_seed(int(step * 10))
+    q = torch.randn(B, N, C, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True) * 8.0
+    k = torch.randn(B, N, C, generator=g) * 0.05
+    v = torch.randn(B, N, C, generator=g)
+    # key j of tile t carries a component along a common direction u that lifts every row's score by
+    # t * step (log2 units) when q has a unit component along u
+    u = torch.zeros(C); u[0] = 1.0
+    q[..., 0] = 4.0                                    # q.u = 4
+    c = (64 ** -0.5) * 1.4426950408889634             # score -> log2 units
+    tile = (torch.arange(N) // 64).float()
+    k[0, :, 0] = tile * step / (4.0 * c)
+    half = (N // 2)
+    k[0, half:, 0] = k[0, half:, 0].flip(0) if step == 5.0 else k[0, half:, 0]   # also a falling tail
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    y = ops.fsa_attention(q.cuda(), k.cuda(), v.cuda(), heads).float().cpu()
+    assert rel(y, ref) < 1.5 * TOL[dtype]
+    row_err = (y - ref).norm(dim=-1) / (ref.norm(dim=-1) + 1e-6)
+    assert float(row_err.max()) < 6 * TOL[dtype], float(row_err.max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,nshot,heads,N", [(2, 1, 2, 256), (1, 3, 1, 192), (3, 2, 2, 100)])
+def test_fsa_attention_lockstep_launch(ops, dtype, b, nshot, heads, N):
+    """n_plain: ONE launch over [support images ; query images] == the bank-fill launch on the support
+    images followed by the bank-reading launch on the queries (A:251-267), bit for bit, and == SDPA."""
+    C = heads * 64
+    n_ref = b * nshot
+    qkv = rnd((n_ref + b, N, 3 * C), dtype, 11).cuda()
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    two = torch.empty(n_ref + b, N, C, dtype=dtype, device="cuda")
+    ops.fsa_attention(q[:n_ref], k[:n_ref], v[:n_ref], heads, out=two[:n_ref])
+    ops.fsa_attention(q[n_ref:], k[n_ref:], v[n_ref:], heads, k[:n_ref], v[:n_ref], nshot=nshot, out=two[n_ref:])
+    one = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=nshot, n_plain=n_ref)
+    assert torch.equal(one, two)
+    sh = lambda t: t.float().reshape(t.shape[0], -1, heads, 64).transpose(1, 2)
+    kq = torch.cat([k[n_ref:], k[:n_ref].reshape(b, nshot * N, C)], dim=1)
+    vq = torch.cat([v[n_ref:], v[:n_ref].reshape(b, nshot * N, C)], dim=1)
+    ref_q = F.scaled_dot_product_attention(sh(q[n_ref:]), sh(kq), sh(vq)).transpose(1, 2).reshape(b, N, C)
+    ref_s = F.scaled_dot_product_attention(sh(q[:n_ref]), sh(k[:n_ref]), sh(v[:n_ref])).transpose(1, 2).reshape(n_ref, N, C)
+    assert rel(one[n_ref:], ref_q) < 1.5 * TOL[dtype] and rel(one[:n_ref], ref_s) < 1.5 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("L", [2, 77])
 def test_cross_attention(ops, dtype, L):
     B, heads, N = 2, 3, 300
