@@ -326,39 +326,71 @@ __global__ void timestep_embedding_kernel(const float* t, T* out, int B, int dim
 
 // ---------------------------------------------------------------------------------------------
 // Segmentation post-processing.  Pass 1: uint8 image + per-image max.  Pass 2: threshold + counts.
+__device__ __forceinline__ uint32_t seg_quant(float v) {
+  v = fminf(fmaxf(v, -1.0f), 1.0f);
+  v = (v * 0.5f + 0.5f) * 255.0f;
+  v = fminf(fmaxf(v, 0.0f), 255.0f);
+  return (uint32_t)v;  // truncation == numpy astype(uint8) on [0,255]
+}
+
+// 4 values per thread (float4 in, one 32-bit store out) when per_img % 4 == 0; scalar otherwise.
 __global__ __launch_bounds__(256) void seg_u8_kernel(const float* x, uint8_t* u8, uint32_t* mx, int per_img) {
   const int b = blockIdx.y;
   uint32_t m = 0;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < per_img; e += gridDim.x * 256) {
-    float v = x[(size_t)b * per_img + e];
-    v = fminf(fmaxf(v, -1.0f), 1.0f);
-    v = (v * 0.5f + 0.5f) * 255.0f;
-    v = fminf(fmaxf(v, 0.0f), 255.0f);
-    const uint32_t q = (uint32_t)v;  // truncation == numpy astype(uint8) on [0,255]
-    u8[(size_t)b * per_img + e] = (uint8_t)q;
-    m = max(m, q);
+  const float* xb = x + (size_t)b * per_img;
+  uint8_t* ub = u8 + (size_t)b * per_img;
+  if ((per_img & 3) == 0 && (((uintptr_t)xb & 15) == 0) && (((uintptr_t)ub & 3) == 0)) {
+    const int n4 = per_img >> 2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n4; e += gridDim.x * 256) {
+      const f32x4 v = *(const f32x4*)(xb + 4 * (size_t)e);
+      const uint32_t q0 = seg_quant(v[0]), q1 = seg_quant(v[1]), q2 = seg_quant(v[2]), q3 = seg_quant(v[3]);
+      *(uint32_t*)(ub + 4 * (size_t)e) = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+      m = max(max(m, q0), max(max(q1, q2), q3));
+    }
+  } else {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_img; e += gridDim.x * 256) {
+      const uint32_t q = seg_quant(xb[e]);
+      ub[e] = (uint8_t)q;
+      m = max(m, q);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(mx + b, m);
 }
 
+// pred = mean_c(u8 / 255) > thr, same fp32 expressions as the reference's to_tensor + mean
+// (byte / 255.0f through a per-block table: 256 IEEE divisions per block instead of 3 per pixel).
 __global__ __launch_bounds__(256) void seg_count_kernel(const uint8_t* u8, const uint8_t* gt, const uint32_t* mx,
                                                         long long* counts, int HW, float r_thr) {
+  __shared__ float lut[256];
+  lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
   const int b = blockIdx.y;
   const float thr = ((float)mx[b] / 255.0f) * r_thr;
   // inter0, inter1, pred0, pred1, gt0, gt1
   unsigned c[6] = {0, 0, 0, 0, 0, 0};
   const uint8_t* ub = u8 + (size_t)b * 3 * HW;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += gridDim.x * 256) {
-    const float t0 = (float)ub[e] / 255.0f, t1 = (float)ub[HW + e] / 255.0f, t2 = (float)ub[2 * HW + e] / 255.0f;
-    const float mean = ((t0 + t1) + t2) / 3.0f;
-    const int g = gt[(size_t)b * HW + e];
-    if (g == 255) continue;  // ignore index: dropped from every histogram
+  const uint8_t* gb = gt + (size_t)b * HW;
+  auto pixel = [&](uint32_t u0, uint32_t u1, uint32_t u2, uint32_t g) {
+    if (g == 255) return;  // ignore index: dropped from every histogram
+    const float mean = ((lut[u0] + lut[u1]) + lut[u2]) / 3.0f;
     const int pr = mean > thr ? 1 : 0;
     c[2 + pr]++;
     c[4 + (g ? 1 : 0)]++;
     if (pr == (g ? 1 : 0)) c[pr]++;
+  };
+  if ((HW & 3) == 0 && (((uintptr_t)ub | (uintptr_t)gb) & 3) == 0) {
+    const int n4 = HW >> 2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n4; e += gridDim.x * 256) {
+      const uint32_t w0 = *(const uint32_t*)(ub + 4 * (size_t)e), w1 = *(const uint32_t*)(ub + HW + 4 * (size_t)e);
+      const uint32_t w2 = *(const uint32_t*)(ub + 2 * (size_t)HW + 4 * (size_t)e), wg = *(const uint32_t*)(gb + 4 * (size_t)e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        pixel((w0 >> (8 * k)) & 255u, (w1 >> (8 * k)) & 255u, (w2 >> (8 * k)) & 255u, (wg >> (8 * k)) & 255u);
+    }
+  } else {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += gridDim.x * 256) pixel(ub[e], ub[HW + e], ub[2 * HW + e], gb[e]);
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -487,15 +519,17 @@ extern "C" int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_
   const int HW = H * Wd, per_img = 3 * HW;
   hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * sizeof(uint32_t), st);
   if (e != hipSuccess) return (int)e;
-  int bx = (per_img + 255) / 256;
+  int bx = (per_img / 4 + 255) / 256;
   if (bx > 512) bx = 512;
+  if (bx < 1) bx = 1;
   hipLaunchKernelGGL(seg_u8_kernel, dim3(bx, B), dim3(256), 0, st, x, seg_u8, scratch, per_img);
   DFW_CHECK_LAUNCH();
   if (gt) {
     e = hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int64_t), st);
     if (e != hipSuccess) return (int)e;
-    int cx = (HW + 255) / 256;
+    int cx = (HW / 4 + 255) / 256;
     if (cx > 256) cx = 256;
+    if (cx < 1) cx = 1;
     hipLaunchKernelGGL(seg_count_kernel, dim3(cx, B), dim3(256), 0, st, (const uint8_t*)seg_u8, gt,
                        (const uint32_t*)scratch, (long long*)counts, HW, r_threshold);
     DFW_CHECK_LAUNCH();
