@@ -221,6 +221,8 @@ def main():
         for name, (n, fl, t) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
             log(f"[roofline] {name:40s} launches {n:4d}  {t * 1e3:8.3f} ms  {fl / t / 1e12:7.1f} TFLOP/s  "
                 f"avg {t / n * 1e6:8.1f} us  ({100 * t / tot_t:4.1f}% of GEMM time)")
+        attn = agg.pop("fsa_attention", None)   # reported beside the dominant GEMM kernel (north_star)
+        tot_t = sum(v[2] for v in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         n, fl, t = dom[1]
         ach = fl / t / 1e12
@@ -237,6 +239,14 @@ def main():
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic, launches_per_step=n,
                     avg_launch_us=round(t / n * 1e6, 2), flops_per_launch=fl / n,
                     gemm_time_share_of_step=round(tot_t / (elapsed / args.steps), 3))
+        if attn is not None:
+            an, afl, at = attn
+            # KV-fusion self-attention launches (QK^T + PV on MFMA, head_dim 64): the roofline north_star
+            # quotes; same live HIP-event timing, algorithmic flops = 4 * 64 * heads * n_q * keys per image
+            roof["attention"] = dict(kernel="fsa_ring_kernel", achieved=round(afl / at / 1e12, 2),
+                                     peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                     frac=round(afl / at / 1e12 / MFMA_PEAK_TFLOPS, 4), launches_per_step=an,
+                                     ms_per_step=round(at * 1e3, 3))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

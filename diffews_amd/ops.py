@@ -227,6 +227,14 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
         a.ldkb, a.ldvb, a.kb_bs, a.vb_bs = k_bank.stride(1), v_bank.stride(1), k_bank.stride(0), v_bank.stride(0)
     a.scale = scale if scale is not None else 64 ** -0.5
     a.dtype, a.n_plain = _dt(q), n_plain
+    if gemm_hook is not None:   # bench.py roofline leg: QK^T + PV flops of this launch
+        keys = n_plain * k.shape[1] + (B - n_plain) * (k.shape[1] + (nshot * k_bank.shape[1] if nshot else 0))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().dfw_fsa_attention(C.byref(a), _stream()), "dfw_fsa_attention")
+        e1.record()
+        gemm_hook("fsa_attention", 4.0 * heads * 64 * N * keys, e0, e1, (B, heads, N, keys))
+        return out
     L.check(L.lib().dfw_fsa_attention(C.byref(a), _stream()), "dfw_fsa_attention")
     return out
 
