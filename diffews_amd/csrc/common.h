@@ -95,7 +95,7 @@ __device__ __forceinline__ u32x4 make_srd(const void* p, uint32_t bytes) {
 // asm); s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
 __device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t lds_byte) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(lds_byte), "v"(voff), "s"(srd) : "memory");
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(voff), "s"(srd) : "memory");
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {

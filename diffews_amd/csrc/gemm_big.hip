@@ -17,12 +17,23 @@
 // Wave tile: (256/WGM) x 64, v_mfma_f32_32x32x16, D[n][m] orientation (lane owns 4 contiguous
 // output channels), same epilogue as gemm.hip.
 #include "gemm_common.h"
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
 namespace dfw {
 
-template <typename T, int BM, int BN, int BK, int S, int OCC, bool CONV>
+// PP (ping-pong): the two waves of every SIMD (wave w and w + 4) run half a K-step apart, two barriers
+// per K-step: while waves 0-3 issue their 16 MFMAs from registers, waves 4-7 read the stage's 12
+// fragments from LDS, and vice versa -- the MFMA pipe always has exactly one wave feeding it and the
+// LDS reads are never in its way.  With all eight waves in the same phase (PP = false) a K-step costs
+// LDS phase + MFMA phase instead of their maximum (0.93 -> see DESIGN.md for the measured gain).
+//   waves 0-3:        reads(k) | B2k | issue(k+3) mfma(k) wait | B2k+1 | reads(k+1) ...
+//   waves 4-7:                 | B2k | issue(k+3) reads(k) wait | B2k+1 | mfma(k)   | B2k+2 ...
+// RAW: every wave's counted wait for stage k+1 sits before B2k+1, its first reader starts after it.
+// WAR: stage k+3 overwrites the slot of stage k-1, whose last reads (waves 4-7, between B2k-2 and
+// B2k-1) were retired by the lgkmcnt wait in front of their MFMAs, i.e. before B2k.
+template <typename T, int BM, int BN, int BK, int S, int OCC, bool CONV, bool PP>
 __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   // S ring stages (S-1 in flight); OCC workgroups per CU (2 * OCC waves per SIMD)
   constexpr int CH = BK / 8, RB = BK * 2;       // 16-byte chunks per row, bytes per row
@@ -320,6 +331,91 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   int rs = 0, ws = 0;
 #pragma unroll
   for (int i = 0; i < S - 1; ++i) { issue(i, ws); ws = nxt(ws); }
+  if constexpr (PP) {
+    static_assert(OCC == 1 && BK == 32, "ping-pong schedule: one workgroup per CU, two k-slices per stage");
+    typename Tr<T>::v8 fa[2][MB], fw[2][NB];
+    auto reads = [&](int slot) {
+      const char* buf = smem + slot * STAGE;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[s2][i] = as_v8<T>(*(const i32x4*)(buf + (lds_ra[i] ^ (s2 << 5))));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fw[s2][j] = as_v8<T>(*(const i32x4*)(buf + (lds_rw[j] ^ (s2 << 5))));
+      }
+    };
+    auto mfmas = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = Tr<T>::mfma(fw[s2][j], fa[s2][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // two fully separate instruction streams for the K loop of a tile (no per-step branches on the
+    // wave group); the epilogue stays common code so that it is inlined once and the accumulators
+    // stay in registers
+    bool has_next = false;
+    int ti_next = 0;
+    auto kloop = [&](auto G1) __attribute__((always_inline)) {
+      constexpr bool g1 = decltype(G1)::value;
+      for (int k = 0; k < nks - (S - 1); ++k) {
+        if constexpr (!g1) reads(rs);
+        bar();
+        issue(k + S - 1, ws);
+        ws = nxt(ws);
+        if constexpr (g1) reads(rs);
+        else mfmas();
+        wait_vm<(S - 2) * DPS>();
+        bar();
+        if constexpr (g1) mfmas();
+        rs = nxt(rs);
+      }
+      if (has_next) setup_loader(tile_coords(tile0 + (ti_next) * nxb));
+#pragma unroll
+      for (int j = 0; j < S - 1; ++j) {
+        if constexpr (!g1) reads(rs);
+        bar();
+        if (has_next) { issue(j, ws); ws = nxt(ws); }
+        if constexpr (g1) reads(rs);
+        else mfmas();
+        // the next step's stage: with a next tile the ring stays S-1 deep, otherwise it drains
+        const int younger = has_next ? S - 2 : S - 3 - j;
+        if (younger >= 2) wait_vm<2 * DPS>();
+        else if (younger == 1) wait_vm<DPS>();
+        else wait_vm<0>();
+        bar();
+        if constexpr (g1) mfmas();
+        rs = nxt(rs);
+      }
+    };
+    wait_vm<(S - 2) * DPS>();                    // stage 0 of the first tile
+    bar();
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      has_next = ti + 1 < my_tiles;
+      ti_next = ti + 1;
+      zero_acc();
+      if (wave >= 4) kloop(std::true_type{});
+      else kloop(std::false_type{});
+      char* stg = nullptr;
+      if constexpr (kStage) {
+        bar();                                     // waves 4-7 are done reading the last stage
+        stg = smem + (rs == 0 ? S - 1 : rs - 1) * STAGE + wave * 4096;
+      }
+      epilogue(ct, stg, tile0 + ti * nxb);
+      if (has_next) ct = tile_coords(tile0 + (ti + 1) * nxb);
+      else ws = rs;
+    }
+    return;
+  }
   for (int ti = 0; ti < my_tiles; ++ti) {
     const bool has_next = ti + 1 < my_tiles;
     zero_acc();
@@ -352,7 +448,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   }
 }
 
-template <typename T, int BM, int BN, int BK, int S, int OCC>
+template <typename T, int BM, int BN, int BK, int S, int OCC, bool PP = false>
 static int launch_big(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.ntm = (p.M + BM - 1) / BM;
@@ -373,11 +469,11 @@ static int launch_big(const GemmP& p, hipStream_t st) {
   dim3 grid(nwg, zdim);
   static bool attr_set[2] = {false, false};
   if (p.taps == 1) {
-    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, false>;
+    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, false, PP>;
     if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = true; }
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   } else {
-    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, true>;
+    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, true, PP>;
     if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = true; }
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   }
@@ -440,8 +536,15 @@ int launch_gemm_big(const GemmP& p, hipStream_t st) {
   if (!gemm_big_eligible(p, bm, bn, bk)) return DFW_ESHAPE;
   const bool bf = p.dtype_bf16 != 0;
   if (bk > 1000) return bf ? launch_big<__bf16, 256, 128, 32, 3, 2>(p, st) : launch_big<_Float16, 256, 128, 32, 3, 2>(p, st);
-  if (bm == 256 && bn == 256) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1>(p, st);
-  if (bm == 512) return bf ? launch_big<__bf16, 512, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1>(p, st);
+  static const char* nopp = getenv("DFW_BIG_NOPP");   // A/B switch for the ping-pong schedule
+  if (bm == 256 && bn == 256) {
+    if (nopp) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1>(p, st);
+    return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true>(p, st);
+  }
+  if (bm == 512) {
+    if (nopp) return bf ? launch_big<__bf16, 512, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1>(p, st);
+    return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true>(p, st);
+  }
   if (bk == 64) return bf ? launch_big<__bf16, 256, 128, 64, 3, 1>(p, st) : launch_big<_Float16, 256, 128, 64, 3, 1>(p, st);
   return bf ? launch_big<__bf16, 256, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 128, 32, 4, 1>(p, st);
 }
