@@ -461,8 +461,8 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
     return 0;
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
-    snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn, big_bk,
-             a->taps == 9 ? "conv" : "lin");
+    snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d%s,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,
+             big_bk % 1000, big_bk > 1000 ? "x2" : "", a->taps == 9 ? "conv" : "lin");
     return 0;
   }
   snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>%s", a->dtype == DFW_BF16 ? "bf16" : "f16", p.plan_bm, p.plan_bn,

@@ -487,18 +487,20 @@ static int launch_big(const GemmP& p, hipStream_t st) {
 // 256x128x64 (3-stage ring, 128-byte rows = full cache lines per DMA lane group), 256x128x32.
 struct BigCfg { int bm, bn, bk, occ; };
 static bool big_cfg_ok(const GemmP& p, const BigCfg& c) {
-  if ((p.N % c.bn) != 0 || (p.K % c.bk) != 0 || (p.Cin % c.bk) != 0) return false;
+  // the 128x128 configuration stores through epi_block (per-quad column guards): ragged N is fine
+  if (c.bm == 128 ? (p.N % 8) != 0 : (p.N % c.bn) != 0) return false;
+  if ((p.K % c.bk) != 0 || (p.Cin % c.bk) != 0) return false;
   if (p.K / c.bk < 4) return false;
   if (p.taps == 9 && (p.Wo % 16 != 0 || p.Ho % (c.bm / 16) != 0)) return false;
   const long long z = p.batch > 1 ? p.batch : 1;
-  return (long long)((p.M + c.bm - 1) / c.bm) * (p.N / c.bn) * z >= 192;
+  return (long long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * z >= (c.occ == 2 ? 256 : 192);
 }
 
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   static const char* off = getenv("DFW_GEMM_NOBIG");
   static const char* force = getenv("DFW_BIG_CFG");   // experiments: "256x128x64"
   if (off) return false;
-  if (p.splitk > 1 || (p.N % 128) != 0) return false;
+  if (p.splitk > 1 || (p.N % 8) != 0) return false;
   if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE) return false;
   if (force) {
     BigCfg c;
@@ -510,12 +512,25 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   }
   static const BigCfg wide[] = {{256, 256, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
   static const BigCfg narrow[] = {{512, 128, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
-  const BigCfg* list = (p.N % 256) == 0 ? wide : narrow;
-  for (int i = 0; i < 3; ++i)
-    if (big_cfg_ok(p, list[i])) {
-      bm = list[i].bm; bn = list[i].bn; bk = list[i].bk;
-      return true;
-    }
+  if ((p.N % 128) == 0) {
+    const BigCfg* list = (p.N % 256) == 0 ? wide : narrow;
+    for (int i = 0; i < 3; ++i)
+      if (big_cfg_ok(p, list[i])) {
+        bm = list[i].bm; bn = list[i].bn; bk = list[i].bk;
+        return true;
+      }
+  }
+  // Experiment (DFW_BIG_SMALL=1): the UNet's K = 320...1280 projections on 128x128 tiles, two
+  // workgroups per CU, the same 4-stage ring -- six stages in flight per CU instead of gemm.hip's two.
+  // Measured neutral (3.19 vs 3.16 ms over the 110 linear launches of a step, scratch/bench_lin.py):
+  // those launches sit at 20-25 us whatever the staging depth (2.5 tile rounds of 5-20 K-steps each,
+  // ramp and tail dominate), so gemm.hip's cost-model tiles stay the default for them.
+  static const char* small = getenv("DFW_BIG_SMALL");
+  static const BigCfg sm = {128, 128, 32, 2};
+  if (small && small[0] == '1' && p.taps == 1 && !p.geglu && big_cfg_ok(p, sm)) {
+    bm = 128; bn = 128; bk = 32 + 1000;
+    return true;
+  }
   return false;
 }
 
@@ -535,6 +550,7 @@ int launch_gemm_big(const GemmP& p, hipStream_t st) {
   int bm = 0, bn = 0, bk = 0;
   if (!gemm_big_eligible(p, bm, bn, bk)) return DFW_ESHAPE;
   const bool bf = p.dtype_bf16 != 0;
+  if (bk > 1000 && bm == 128) return bf ? launch_big<__bf16, 128, 128, 32, 4, 2>(p, st) : launch_big<_Float16, 128, 128, 32, 4, 2>(p, st);
   if (bk > 1000) return bf ? launch_big<__bf16, 256, 128, 32, 3, 2>(p, st) : launch_big<_Float16, 256, 128, 32, 3, 2>(p, st);
   static const char* nopp = getenv("DFW_BIG_NOPP");   // A/B switch for the ping-pong schedule
   if (bm == 256 && bn == 256) {
