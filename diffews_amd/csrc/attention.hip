@@ -15,8 +15,16 @@
 //                   fragments come from the row-major V tile via ds_read_b64_tr_b16.
 // fp32 accumulation and fp32 softmax statistics throughout.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
+
+#ifndef DFW_FSA_PRIO
+#define DFW_FSA_PRIO 1
+#endif
+#ifndef DFW_FSA_ANTIPHASE
+#define DFW_FSA_ANTIPHASE 0   // measured: 398 vs 380 us on the 64x64-level lock-step launch -- off
+#endif
 
 namespace dfw {
 
@@ -288,6 +296,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   // every K / V fragment read from LDS feeds two MFMAs.
   constexpr int KT = 64, S = 4;
   constexpr float kDefer = 8.0f;            // see the online softmax below
+  constexpr bool kPrio = DFW_FSA_PRIO;
   constexpr int TILE = KT * 128;            // bytes of one K (or V) tile
   constexpr int STAGE = 2 * TILE;
   constexpr int DPS = 16 / NW;              // DMA wave-instructions per stage per wave (K + V)
@@ -394,19 +403,8 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   // here (the first tiles are needed by the first iteration anyway) removes them from the loop.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   int c_tt = 0, c_own = 1;  // compute-side tile-in-segment / own-segment flag
-  for (int t = 0; t < ntiles; ++t) {
-    const int younger = issued - t - 1;
-    if (younger >= 2) wait_vm<2 * DPS>();
-    else if (younger == 1) wait_vm<DPS>();
-    else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (issued < ntiles) { issue(issued & (S - 1)); ++issued; }
-    const char* kbuf = smem + (t & (S - 1)) * STAGE;
-    const char* vbuf = kbuf + TILE;
-    const int nvalid = (c_own ? p.n_kv : p.n_bank) - c_tt * KT;
-    if (++c_tt == (c_own ? tiles_own : tiles_bank)) { c_tt = 0; c_own = 0; }
-
+  typename Tr<T>::v8 pf[QB][4];   // P^T fragments of the tile between its softmax and its P.V
+  auto qk_softmax = [&](const char* kbuf, int nvalid) __attribute__((always_inline)) {
     // ---- S^T = K . Q^T  (each K fragment feeds QB MFMAs)
     f32x16 s[QB][2];
 #pragma unroll
@@ -415,6 +413,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[g][kb][r] = 0.f;
+    if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
 #pragma unroll
         for (int g = 0; g < QB; ++g) s[g][kb] = Tr<T>::mfma(kf, qf[g][ss], s[g][kb]);
       }
-    typename Tr<T>::v8 pf[QB][4];
+    if (kPrio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int g = 0; g < QB; ++g) {
       if (nvalid < KT) {
@@ -477,7 +476,10 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
           for (int j = 0; j < 8; ++j) pf[g][kb * 2 + t2][j] = (T)s[g][kb][8 * t2 + j];
     }
 
+  };
+  auto pv = [&](const char* vbuf) __attribute__((always_inline)) {
     // ---- O^T += V^T . P^T  (each V^T fragment feeds QB MFMAs)
+    if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -495,6 +497,65 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
           for (int g = 0; g < QB; ++g) o[g][d] = Tr<T>::mfma(vf, pf[g][kb * 2 + t2], o[g][d]);
         }
       }
+    if (kPrio) __builtin_amdgcn_s_setprio(0);
+  };
+  auto wait_tile = [&](int t) __attribute__((always_inline)) {
+    const int younger = issued - t - 1;
+    if (younger >= 2) wait_vm<2 * DPS>();
+    else if (younger == 1) wait_vm<DPS>();
+    else wait_vm<0>();
+  };
+  auto bar = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto next_nvalid = [&]() __attribute__((always_inline)) {
+    const int nv = (c_own ? p.n_kv : p.n_bank) - c_tt * KT;
+    if (++c_tt == (c_own ? tiles_own : tiles_bank)) { c_tt = 0; c_own = 0; }
+    return nv;
+  };
+  // Anti-phase schedule (8 waves, one query block each): waves w and w+4 share a SIMD; waves 0-3 run
+  // [QK^T, softmax | P.V] and waves 4-7 [P.V of the previous tile | QK^T, softmax] around a second
+  // barrier per tile, so while one wave of a SIMD is in its ~700 issue cycles of softmax VALU the other
+  // one owns the MFMA pipe.  Built and parity-tested, but SLOWER on MI355X (-4.5 %: with four waves per
+  // SIMD from two workgroups the phases already interleave, and the second barrier costs more than the
+  // forced alternation gains), so it is compiled out by default (DFW_FSA_ANTIPHASE).  s_setprio(1)
+  // around the two MFMA chains, by contrast, is worth +9 % (413 -> 380 us).  Ring ordering: every wave's counted wait for tile t sits before the
+  // tile's first barrier (first reader: waves 0-3 right after it); tile t+3 overwrites the slot of tile
+  // t-1 only after the second barrier, behind which no wave still reads it.
+  constexpr bool kAnti = (NW == 8 && QB == 1 && DFW_FSA_ANTIPHASE);
+  if constexpr (kAnti) {
+    auto loop = [&](auto GB) __attribute__((always_inline)) {
+      constexpr bool gb = decltype(GB)::value;
+      const char* vprev = smem;
+      for (int t = 0; t < ntiles; ++t) {
+        wait_tile(t);
+        bar();
+        const char* kbuf = smem + (t & (S - 1)) * STAGE;
+        const int nvalid = next_nvalid();
+        if constexpr (!gb) qk_softmax(kbuf, nvalid);
+        else if (t > 0) pv(vprev);
+        bar();
+        if (issued < ntiles) { issue(issued & (S - 1)); ++issued; }
+        if constexpr (!gb) pv(kbuf + TILE);
+        else qk_softmax(kbuf, nvalid);
+        vprev = kbuf + TILE;
+      }
+      bar();
+      if constexpr (gb) pv(vprev);
+    };
+    if (wave >= NW / 2) loop(std::true_type{});
+    else loop(std::false_type{});
+  } else {
+    for (int t = 0; t < ntiles; ++t) {
+      wait_tile(t);
+      bar();
+      if (issued < ntiles) { issue(issued & (S - 1)); ++issued; }
+      const char* kbuf = smem + (t & (S - 1)) * STAGE;
+      const int nvalid = next_nvalid();
+      qk_softmax(kbuf, nvalid);
+      pv(kbuf + TILE);
+    }
   }
 
 #pragma unroll
