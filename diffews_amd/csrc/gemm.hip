@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto compute = [&](const char* buf) {
+      __builtin_amdgcn_s_setprio(1);   // the co-resident workgroup's loads / epilogue yield to this MFMA run
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         typename Tr<T>::v8 fa[MB], fw[NB];
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
           for (int j = 0; j < NB; ++j) acc[i][j] = Tr<T>::mfma(fw[j], fa[i], acc[i][j]);
       }
+      __builtin_amdgcn_s_setprio(0);
     };
     for (int ks = ks0; ks + 1 < ks1; ++ks) {
       issue_loads(ks + 1, smem + (cur ^ 1) * BUF);   // lands in the other buffer during the MFMAs

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = Tr<T>::mfma(fw[j], fa[i], acc[i][j]);
     }
+    __builtin_amdgcn_s_setprio(0);
   };
   auto retire_and_sync = [&](int younger) {
     // this wave's DMA of the stage about to be read is done once at most the `younger` stages'
