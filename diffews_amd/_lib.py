@@ -82,6 +82,7 @@ SYMBOLS = {
     "dfw_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),
     "dfw_conv_small": (_i32, [C.POINTER(ConvSmallArgs), _vp]),
     "dfw_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "dfw_softmax_groups": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dfw_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dfw_concat_channels": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dfw_timestep_embedding": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),

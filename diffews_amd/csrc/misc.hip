@@ -325,6 +325,32 @@ __global__ void timestep_embedding_kernel(const float* t, T* out, int B, int dim
 }
 
 // ---------------------------------------------------------------------------------------------
+// Softmax over `L` consecutive fp32 scores per (row, group) -> T probabilities; columns >= groups*L
+// of the ld-wide output row are zeroed.  Used by the folded prompt attention (L = 2 prompt tokens,
+// groups = heads): the scores row is [heads*L <= ld] wide.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_groups_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                             long long rows, int ld, int groups, int L) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = ld / L;                       // slots per row, including the zeroed padding
+  if (e >= rows * per_row) return;
+  const long long r = e / per_row;
+  const int g = (int)(e - r * per_row);
+  const float* xi = x + r * ld + (long long)g * L;
+  T* yo = y + r * ld + (long long)g * L;
+  if (g >= groups) {
+    for (int l = 0; l < L; ++l) yo[l] = (T)0.f;
+    return;
+  }
+  float m = xi[0];
+  for (int l = 1; l < L; ++l) m = fmaxf(m, xi[l]);
+  float sum = 0.f;
+  for (int l = 0; l < L; ++l) sum += __expf(xi[l] - m);
+  const float inv = 1.0f / sum;
+  for (int l = 0; l < L; ++l) yo[l] = (T)(__expf(xi[l] - m) * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Segmentation post-processing.  Pass 1: uint8 image + per-image max.  Pass 2: threshold + counts.
 __device__ __forceinline__ uint32_t seg_quant(float v) {
   v = fminf(fmaxf(v, -1.0f), 1.0f);
@@ -469,6 +495,20 @@ extern "C" int dfw_softmax_rows(const float* x, void* y, int64_t rows, int32_t L
     else hipLaunchKernelGGL((softmax_rows_reg_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, st, x, (_Float16*)y, L, c);
   } else if (dtype == DFW_BF16) hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, st, x, (__bf16*)y, L, c);
   else hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, st, x, (_Float16*)y, L, c);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_softmax_groups(const float* x, void* y, int64_t rows, int32_t ld, int32_t groups, int32_t L,
+                                  int32_t dtype, dfw_stream_t stream) {
+  if (!x || !y || rows <= 0 || ld <= 0 || groups <= 0 || L <= 0) return DFW_EINVAL;
+  if (ld % L != 0 || groups * L > ld) return DFW_ESHAPE;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  const long long total = rows * (ld / L);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((softmax_groups_kernel<__bf16>), grid, dim3(256), 0, st, x, (__bf16*)y, (long long)rows, ld, groups, L);
+  else hipLaunchKernelGGL((softmax_groups_kernel<_Float16>), grid, dim3(256), 0, st, x, (_Float16*)y, (long long)rows, ld, groups, L);
   DFW_CHECK_LAUNCH();
   return 0;
 }

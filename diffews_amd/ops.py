@@ -328,6 +328,15 @@ def softmax_rows(x, dtype, scale=1.0):
     return y
 
 
+def softmax_groups(x, groups, L_, dtype):
+    """x [rows, ld] fp32 scores -> [rows, ld] `dtype`: softmax over each group's L entries, padding zeroed."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().dfw_softmax_groups(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], groups, L_,
+                                       _DT[dtype], _stream()), "dfw_softmax_groups")
+    return y
+
+
 def transpose(x):
     assert x.dim() == 3 and x.is_contiguous()
     Bt, R, Cc = x.shape

@@ -14,6 +14,8 @@ NHWC storage-dtype tensors, so the NCHW<->token permutes of Transformer2DModel v
 """
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -88,6 +90,28 @@ class _Transformer:
         self.k_bank = None
         self.v_bank = None
         self.kv_slice = (0, 2 * self.w_q2.shape[0])   # column range in the fused prompt-K/V buffer
+        self.fold2 = None   # (G [64, C], U^T [C, 64], L): attn2 folded on a constant prompt (fold_attn2)
+
+    def fold_attn2(self, kv, L_ctx):
+        """attn2 on a CONSTANT prompt: with keys/values fixed, per head h and prompt token l
+            score[h,l] = LN(x) . g[h,l],   g[h,l] = scale * Wq[h]^T k[l,h]      (one [64, C] matrix G)
+            out        = sum_{h,l} softmax_l(score)[h,l] * u[h,l] + b_o,   u[h,l] = Wo[:, h] v[l,h]
+        so to_q (C x C), the attention kernel and to_out (C x C) collapse into two thin GEMMs (N = 64 and
+        K = 64) around a per-head softmax over the L prompt tokens.  kv: this layer's [L, 2C] slice of the
+        folded prompt K/V.  Needs heads * L <= 64 (L = 2 at inference, P:591-600)."""
+        C, h = self.w_q2.shape[0], self.heads
+        if h * L_ctx > 64:
+            self.fold2 = None
+            return
+        k, v = kv[:, :C].float(), kv[:, C:2 * C].float()            # [L, C]
+        wq, wo = self.w_q2.float(), self.w_o2.float()               # [C_out, C_in]
+        G = torch.zeros(64, C, dtype=torch.float32, device=kv.device)
+        Ut = torch.zeros(C, 64, dtype=torch.float32, device=kv.device)
+        for hh in range(h):
+            blk = slice(hh * 64, (hh + 1) * 64)
+            G[hh * L_ctx:(hh + 1) * L_ctx] = (64 ** -0.5) * (k[:, blk] @ wq[blk, :])       # [L, C]
+            Ut[:, hh * L_ctx:(hh + 1) * L_ctx] = wo[:, blk] @ v[:, blk].t()                # [C, L]
+        self.fold2 = (G.to(self.w_q2.dtype).contiguous(), Ut.to(self.w_q2.dtype).contiguous(), L_ctx)
 
     def clear_bank(self):
         self.k_bank = None
@@ -124,16 +148,22 @@ class _Transformer:
         t = ops.linear(att.view(-1, C), self.w_o1, bias=self.b_o1, residual=t)
         # --- attn2: cross-attention on the prompt tokens
         ln = ops.layernorm(t, *self.ln[1])
-        q2 = ops.linear(ln, self.w_q2).view(B, N, C)
-        # prompt K/V of all 16 layers come from ONE GEMM per forward (MyUNet2DConditionModel._prompt_kv);
-        # this layer's [B, L, 2C] slice is a strided view of that buffer
-        o, kv_all = self.kv_slice[0], ehs2d
-        if isinstance(kv_all, tuple):
-            kv2 = kv_all[1].view(B, L_ctx, -1)[..., o:o + 2 * C]
+        if isinstance(ehs2d, tuple) and len(ehs2d) == 3 and ehs2d[2] and self.fold2 is not None:
+            G, Ut, Lf = self.fold2                                   # constant prompt: see fold_attn2
+            sc = ops.linear(ln, G, out_f32=True)                     # [M, 64] scores (scale folded in)
+            pr = ops.softmax_groups(sc, heads, Lf, x.dtype)          # per-head softmax over the L tokens
+            t = ops.linear(pr, Ut, bias=self.b_o2, residual=t)
         else:
-            kv2 = ops.linear(ehs2d, self.w_kv2).view(B, L_ctx, 2 * C)
-        ca = ops.cross_attention(q2, kv2[..., :C], kv2[..., C:], heads)
-        t = ops.linear(ca.view(-1, C), self.w_o2, bias=self.b_o2, residual=t)
+            q2 = ops.linear(ln, self.w_q2).view(B, N, C)
+            # prompt K/V of all 16 layers come from ONE GEMM per forward (MyUNet2DConditionModel._prompt_kv);
+            # this layer's [B, L, 2C] slice is a strided view of that buffer
+            o, kv_all = self.kv_slice[0], ehs2d
+            if isinstance(kv_all, tuple):
+                kv2 = kv_all[1].view(B, L_ctx, -1)[..., o:o + 2 * C]
+            else:
+                kv2 = ops.linear(ehs2d, self.w_kv2).view(B, L_ctx, 2 * C)
+            ca = ops.cross_attention(q2, kv2[..., :C], kv2[..., C:], heads)
+            t = ops.linear(ca.view(-1, C), self.w_o2, bias=self.b_o2, residual=t)
         # --- GEGLU feed-forward
         ln = ops.layernorm(t, *self.ln[2])
         ff = ops.linear(ln, self.w_ff1, bias=self.b_ff1, geglu=True)
@@ -235,6 +265,8 @@ class MyUNet2DConditionModel:
             t.kv_slice = (off, t.w_kv2.shape[0])
             off += t.w_kv2.shape[0]
         self.kv_w_all = torch.cat(kvw, 0).contiguous()
+        # fold_conditioning() also folds attn2 on the constant prompt (DFW_NO_ATTN2_FOLD=1: A/B switch)
+        self.fold_attn2 = os.environ.get("DFW_NO_ATTN2_FOLD") is None
 
     def _resnets_with_prefix(self):
         for i, blk in enumerate(self.down):
@@ -351,10 +383,17 @@ class MyUNet2DConditionModel:
         t = float(timestep)
         self._folded = {"t": t, "L": pe.shape[0], "prompt": pe, "tproj": self._time_proj(1, t),
                         "kv": ops.linear(pe, self.kv_w_all), "rows": {}}
+        for tr in self._transformers():
+            tr.fold2 = None
+            if self.fold_attn2:
+                o, n = tr.kv_slice
+                tr.fold_attn2(self._folded["kv"][:, o:o + n], pe.shape[0])
         return self
 
     def unfold_conditioning(self):
         self._folded = None
+        for tr in self._transformers():
+            tr.fold2 = None
 
     def _folded_rows(self, B, timestep):
         f = getattr(self, "_folded", None)
@@ -401,8 +440,9 @@ class MyUNet2DConditionModel:
         return out[n_ref:]
 
     def _trunk(self, x, tproj, ehs2d, L_ctx, n_ref, out_scale, kv_all=None):
-        # all layers' prompt K/V in one launch: [B*L, sum(2C)]; layers take column slices
-        ehs2d = (ehs2d, kv_all if kv_all is not None else ops.linear(ehs2d, self.kv_w_all))
+        # all layers' prompt K/V in one launch: [B*L, sum(2C)]; layers take column slices; the third
+        # entry says the prompt is the folded constant (layers may then use their folded attn2)
+        ehs2d = (ehs2d, kv_all if kv_all is not None else ops.linear(ehs2d, self.kv_w_all), kv_all is not None)
         # ---- 3. down (U:1153-1175)
         skips = [x]
         for blk in self.down:

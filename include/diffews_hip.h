@@ -197,6 +197,11 @@ int dfw_softmax_rows(const float* x, void* y, int64_t rows, int32_t L, float sca
                      dfw_stream_t stream);
 
 /* Batched 2-D transpose of storage-dtype matrices: y[b][c][r] = x[b][r][c]. */
+/* Softmax over L consecutive fp32 scores per (row, group): y[r][g*L + l] = softmax_l(x[r][g*L + l]),
+ * g < groups; the remaining columns of the ld-wide row are zeroed.  The folded attn2 (prompt tokens are
+ * constants of a checkpoint, P:585-601): scores = LN(x) G, probabilities here, out = P U + residual. */
+int dfw_softmax_groups(const float* x, void* y, int64_t rows, int32_t ld, int32_t groups, int32_t L,
+                       int32_t dtype, dfw_stream_t stream);
 int dfw_transpose(const void* x, void* y, int32_t batch, int32_t R, int32_t C, int32_t dtype,
                   dfw_stream_t stream);
 

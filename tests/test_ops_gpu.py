@@ -367,6 +367,17 @@ def test_softmax_transpose_concat_bmm(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,groups,L", [(1000, 5, 2), (64, 20, 2), (300, 10, 4), (7, 1, 64)])
+def test_softmax_groups(ops, dtype, rows, groups, L):
+    """Per-(row, group) softmax over L fp32 scores, zeroed padding (folded prompt attention)."""
+    x = (torch.randn(rows, 64, generator=torch.Generator().manual_seed(rows)) * 3).cuda()
+    y = ops.softmax_groups(x, groups, L, dtype).float().cpu()
+    ref = torch.zeros(rows, 64)
+    ref[:, :groups * L] = torch.softmax(x.cpu()[:, :groups * L].view(rows, groups, L), dim=-1).view(rows, -1)
+    assert rel(y, ref) < TOL[dtype] and float(y[:, groups * L:].abs().max() if groups * L < 64 else 0) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_timestep_embedding(ops, dtype):
     t = torch.tensor([1.0, 500.0, 999.0])
     half = 160
