@@ -57,7 +57,8 @@ class LayerNormArgs(C.Structure):
 class ConvSmallArgs(C.Structure):
     _fields_ = [("x", _vp), ("W", _vp), ("bias", _vp), ("y", _vp),
                 ("B", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("Cout", _i32), ("taps", _i32), ("ldy", _i32),
-                ("in_scale", _f32), ("out_scale", _f32), ("out_mode", _i32), ("dtype", _i32)]
+                ("in_scale", _f32), ("out_scale", _f32), ("out_mode", _i32), ("dtype", _i32),
+                ("gn_partial", _vp), ("gn_groups", _i32)]
 
 
 class ImageArgs(C.Structure):
@@ -81,6 +82,7 @@ SYMBOLS = {
     "dfw_groupnorm_workspace_bytes": (_sz, [C.POINTER(GroupNormArgs)]),
     "dfw_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),
     "dfw_conv_small": (_i32, [C.POINTER(ConvSmallArgs), _vp]),
+    "dfw_conv_small_gn_chunks": (_i32, [C.POINTER(ConvSmallArgs)]),
     "dfw_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "dfw_softmax_groups": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dfw_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -11,6 +11,7 @@ struct CsP {
   int B, Cin, H, Wd, Cout, taps, ldy, out_mode;
   float in_scale, out_scale;
   int iters;   // conv_small8w: pixel groups per thread
+  float* gn_partial; int gn_groups, gn_chunks;   // fused GroupNorm partial sums of the NHWC output (optional)
 };
 
 template <typename T>
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
   const int oct = threadIdx.x & 15;
   if (cb0 + oct * 8 >= p.Cout) return;
   const long long nq = (long long)p.B * p.H * W8;
+  float gsum[8], gsq[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) { gsum[o] = 0.f; gsq[o] = 0.f; }
   // thread = 8 adjacent pixels x 8 channels (each LDS weight read feeds 64 FMAs; with 4 pixels the
   // LDS pipe was as busy as the VALU); p.iters pixel groups per thread amortise the weight staging
   for (int it = 0; it < p.iters; ++it) {
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
     const int b = (int)(q / (p.H * W8)), rem = (int)(q - (long long)b * p.H * W8);
     const int y = rem / W8, x0 = (rem - y * W8) * 8;
     f32x2 acc[8][4];                       // [pixel][channel pair]: packed fp32 FMAs
+    // (fused GroupNorm statistics: host guarantees every thread is live in every iteration)
 #pragma unroll
     for (int px = 0; px < 8; ++px)
 #pragma unroll
@@ -204,7 +209,41 @@ __global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
         v[2 * o] = (acc[px][o][0] + bs[oct * 8 + 2 * o]) * p.out_scale;
         v[2 * o + 1] = (acc[px][o][1] + bs[oct * 8 + 2 * o + 1]) * p.out_scale;
       }
-      *(i32x4*)(p.y + (((size_t)b * HW + pix + px) * p.ldy + cb0 + oct * 8) * sizeof(T)) = pack8<T>(v);
+      const i32x4 pk = pack8<T>(v);
+      *(i32x4*)(p.y + (((size_t)b * HW + pix + px) * p.ldy + cb0 + oct * 8) * sizeof(T)) = pk;
+      if (p.gn_partial) {                 // statistics of the STORED (rounded) values
+        float r[8];
+        unpack8<T>(pk, r);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { gsum[o] += r[o]; gsq[o] += r[o] * r[o]; }
+      }
+    }
+  }
+  if (p.gn_partial) {
+    // [pixel group 0..15][128 channels][2] in LDS, then one thread per group folds channels and pixel
+    // groups in a fixed order: deterministic partial (sum, sum of squares) per (image, workgroup, group)
+    float* red = bs + 128;
+    const int pg = threadIdx.x >> 4;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      red[(pg * 128 + oct * 8 + o) * 2 + 0] = gsum[o];
+      red[(pg * 128 + oct * 8 + o) * 2 + 1] = gsq[o];
+    }
+    __syncthreads();
+    const int cpg = p.Cout / p.gn_groups, gpb = 128 / cpg;      // channels per group, groups per 128-channel block
+    if ((int)threadIdx.x < gpb) {
+      float a = 0.f, a2 = 0.f;
+      for (int g2 = 0; g2 < 16; ++g2)
+        for (int c = threadIdx.x * cpg; c < ((int)threadIdx.x + 1) * cpg; ++c) {
+          a += red[(g2 * 128 + c) * 2 + 0];
+          a2 += red[(g2 * 128 + c) * 2 + 1];
+        }
+      const long long per_blk = 16LL * p.iters, per_img = (long long)p.H * W8;
+      const long long first = (long long)blockIdx.x * per_blk;
+      const int img = (int)(first / per_img), chunk = (int)((first - (long long)img * per_img) / per_blk);
+      float* o2 = p.gn_partial + (((size_t)img * p.gn_chunks + chunk) * p.gn_groups + cb0 / cpg + threadIdx.x) * 2;
+      o2[0] = a;
+      o2[1] = a2;
     }
   }
 }
@@ -438,6 +477,27 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const uint8_t* u8, const
 
 using namespace dfw;
 
+// pixel groups per thread of conv_small8w for this shape (>= ~2048 workgroups in flight)
+static long long cs8w_iters(const dfw_conv_small_args* a) {
+  const long long pix = (long long)a->B * a->H * a->Wd;
+  const long long cblocks = (a->Cout + 127) / 128, groups16 = (pix / 8 + 15) / 16;
+  long long iters = groups16 * cblocks / 2048;
+  return iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+}
+static bool cs8w_ok(const dfw_conv_small_args* a) {
+  return a->Wd % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_mode == DFW_OUT_T && a->Cout % 8 == 0 &&
+         a->taps * a->Cin <= 72 && (a->taps == 9 || a->taps == 1);
+}
+
+extern "C" int32_t dfw_conv_small_gn_chunks(const dfw_conv_small_args* a) {
+  if (!a || a->gn_groups <= 0 || !cs8w_ok(a) || a->Cout % 128 != 0 || a->Cout % a->gn_groups != 0) return 0;
+  const int cpg = a->Cout / a->gn_groups;
+  if (128 % cpg != 0) return 0;
+  const long long per_img = (long long)a->H * (a->Wd / 8), per_blk = 16 * cs8w_iters(a);
+  if (per_img % per_blk != 0) return 0;          // workgroups must not straddle images (and no idle threads)
+  return (int32_t)(per_img / per_blk);
+}
+
 extern "C" int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream) {
   if (!a || !a->x || !a->W || !a->y) return DFW_EINVAL;
   if (a->B <= 0 || a->H <= 0 || a->Wd <= 0 || a->Cout <= 0) return DFW_EINVAL;
@@ -451,12 +511,16 @@ extern "C" int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream)
   p.ldy = a->ldy; p.out_mode = a->out_mode; p.in_scale = a->in_scale; p.out_scale = a->out_scale;
   const long long pix = (long long)a->B * a->H * a->Wd;
   hipStream_t st = (hipStream_t)stream;
-  if (a->Wd % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_mode == DFW_OUT_T && a->Cout % 8 == 0 &&
-      a->taps * a->Cin <= 72 && (a->taps == 9 || a->taps == 1)) {
-    const size_t lds = ((size_t)a->taps * a->Cin + 1) * 128 * sizeof(float);
+  p.gn_partial = nullptr; p.gn_groups = 0; p.gn_chunks = 0;
+  if (a->gn_partial) {
+    p.gn_chunks = dfw_conv_small_gn_chunks(a);
+    if (p.gn_chunks <= 0) return DFW_ESHAPE;     // ask dfw_conv_small_gn_chunks() first
+    p.gn_partial = a->gn_partial; p.gn_groups = a->gn_groups;
+  }
+  if (cs8w_ok(a)) {
+    const size_t lds = ((size_t)a->taps * a->Cin + 1) * 128 * sizeof(float) + (p.gn_partial ? 16 * 128 * 2 * sizeof(float) : 0);
     const long long cblocks = (a->Cout + 127) / 128, groups16 = (pix / 8 + 15) / 16;
-    long long iters = groups16 * cblocks / 2048;   // keep >= ~2048 workgroups in flight
-    iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+    const long long iters = cs8w_iters(a);
     p.iters = (int)iters;
     dim3 grid((unsigned)((groups16 + iters - 1) / iters), (unsigned)cblocks);
     const bool bf = a->dtype == DFW_BF16;

@@ -299,8 +299,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, out_scale=1.0):
-    """Boundary conv with Cin <= 8: x NCHW fp32 [B, Cin, H, W], w fp32 [Cout, taps, Cin]."""
+def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, out_scale=1.0, gn_groups=0):
+    """Boundary conv with Cin <= 8: x NCHW fp32 [B, Cin, H, W], w fp32 [Cout, taps, Cin].
+    gn_groups: also emit the GroupNorm partial sums of the output where the kernel supports it (y._gn_stats)."""
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
     B, Cin, H, W = x.shape
     assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == cout * taps * Cin
@@ -314,7 +315,17 @@ def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, 
     a.in_scale, a.out_scale = in_scale, out_scale
     a.out_mode = L.OUT_NCHW_F32 if nchw_f32_out else L.OUT_T
     a.dtype = _DT[dtype]
+    stats = None
+    if gn_groups and not nchw_f32_out:
+        a.gn_groups = gn_groups
+        chunks = L.lib().dfw_conv_small_gn_chunks(C.byref(a))
+        if chunks > 0:
+            part = torch.empty(B, chunks, gn_groups, 2, dtype=torch.float32, device=x.device)
+            a.gn_partial = part.data_ptr()
+            stats = (part, chunks, gn_groups)
     L.check(L.lib().dfw_conv_small(C.byref(a), _stream()), "dfw_conv_small")
+    if stats is not None:
+        y._gn_stats = stats
     return y
 
 

@@ -97,7 +97,7 @@ class _Encoder:
     @torch.no_grad()
     def __call__(self, x):
         x = x.to(dtype=torch.float32).contiguous()
-        h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt)
+        h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups)
         for res, down in self.blocks:
             for r in res:
                 h = r(h)
@@ -131,7 +131,7 @@ class _Decoder:
     @torch.no_grad()
     def __call__(self, z):
         z = z.to(dtype=torch.float32).contiguous()
-        h = ops.conv_small(z, self.w_in, self.b_in, self.c0, 9, self.dt)
+        h = ops.conv_small(z, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups)
         h = self.mid(h)
         for res, up in self.blocks:
             for r in res:

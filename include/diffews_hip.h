@@ -187,9 +187,14 @@ typedef struct {
   float in_scale, out_scale;
   int32_t out_mode;
   int32_t dtype;
+  /* Optional fused GroupNorm statistics of the NHWC output (the first resnet's norm1 reads them through
+   * dfw_groupnorm_args.pre_partial): gn_partial[B][chunks][gn_groups][2], chunks from
+   * dfw_conv_small_gn_chunks() (0: not supported for this shape -- leave gn_partial NULL). */
+  float* gn_partial; int32_t gn_groups;
 } dfw_conv_small_args;
 
 int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream);
+int32_t dfw_conv_small_gn_chunks(const dfw_conv_small_args* a);
 
 /* Row softmax of fp32 scores -> storage dtype probabilities (VAE mid-block attention, 1 head of
  * dim 512: diffusers Attention.get_attention_scores with upcast_softmax).  y = softmax(x*scale). */

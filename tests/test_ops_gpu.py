@@ -354,6 +354,27 @@ def test_conv_small(ops, dtype, Cin, Cout, taps, nchw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(3, 3, 64, 64, 128), (2, 4, 32, 32, 512), (2, 8, 32, 64, 256), (1, 3, 128, 128, 128)])
+def test_conv_small_fused_groupnorm_stats(ops, dtype, B, Cin, H, W, Cout):
+    """conv_in's epilogue emits the first GroupNorm's partial sums (of the stored, rounded values):
+    groupnorm(y) with them == groupnorm of the same tensor with its own statistics pass."""
+    from diffews_amd.packing import pack_conv_small
+    g = torch.Generator().manual_seed(B * 100 + Cout)
+    x = (torch.rand(B, Cin, H, W, generator=g) * 2 - 1).cuda()
+    w = pack_conv_small(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    gm, bt = (torch.randn(Cout, generator=g) * 0.2 + 1).cuda(), (torch.randn(Cout, generator=g) * 0.2).cuda()
+    y = ops.conv_small(x, w, bias, Cout, 9, dtype, gn_groups=32)
+    assert getattr(y, "_gn_stats", None) is not None, "fused statistics expected for this shape"
+    y0 = ops.conv_small(x, w, bias, Cout, 9, dtype)
+    assert torch.equal(y, y0)
+    fused = ops.groupnorm(y, gm, bt, 32, 1e-6, silu=True)
+    plain = ops.groupnorm(y0, gm, bt, 32, 1e-6, silu=True)
+    ref = F.silu(F.group_norm(y0.float().permute(0, 3, 1, 2), 32, gm, bt, eps=1e-6)).permute(0, 2, 3, 1)
+    assert rel(fused, ref) < TOL[dtype] and rel(fused, plain) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_softmax_transpose_concat_bmm(ops, dtype):
     s = torch.randn(3, 50, 264) * 4
     y = ops.softmax_rows(s.cuda(), dtype, scale=0.3)
