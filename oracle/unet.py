@@ -143,7 +143,7 @@ class OracleUNet(nn.Module):
             timestep = torch.tensor([timestep], dtype=torch.int64, device=sample.device)
         elif timestep.ndim == 0:
             timestep = timestep[None]
-        timestep = timestep.expand(sample.shape[0])
+        timestep = timestep.to(sample.device).expand(sample.shape[0])   # (device-agnostic: tests may run the oracle on the GPU)
         t_emb = timestep_embedding(timestep, cfg["block_out_channels"][0], cfg["flip_sin_to_cos"], cfg["freq_shift"])
         emb = self.time_embedding(t_emb.to(sample.dtype))
         x = self.conv_in(sample) if is_target else self.conv_in_ref(sample)
