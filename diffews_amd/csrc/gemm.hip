@@ -128,8 +128,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
     }
     if constexpr (CONV) {
-      tap = ks0 / p.cpt;
-      cc = ks0 - tap * p.cpt;
+      if (p.conv_chunk_major) {
+        cc = ks0 / 9;
+        tap = ks0 - cc * 9;
+      } else {
+        tap = ks0 / p.cpt;
+        cc = ks0 - tap * p.cpt;
+      }
     }
   };
 
@@ -170,10 +175,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         const uint32_t off = ((a_pix[i] + (uint32_t)(iy * p.Wi + ix)) * (uint32_t)p.lda + coff) * (uint32_t)sizeof(T);
         dma16(ra, ok ? off : kOOB, dst + i * 4096);   // out-of-range lanes write zeros (halo / padding)
       }
-      if (++cc == p.cpt) { cc = 0; ++tap; }
+    }
+    uint32_t koff = (uint32_t)ks * 128u;
+    if constexpr (CONV) {
+      // channel-chunk-major K walk (nine taps of a 64-channel chunk back to back): the shifted re-reads
+      // of the input patch hit L2 one step after the first touch (see gemm_big.hip); split-K ranges are
+      // contiguous runs of this walk
+      koff = (uint32_t)(tap * p.Cin + cc * 64) * (uint32_t)sizeof(T);
+      if (p.conv_chunk_major) {
+        if (++tap == 9) { tap = 0; ++cc; }
+      } else {
+        if (++cc == p.cpt) { cc = 0; ++tap; }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + (uint32_t)ks * 128u, dst + BM * 128 + i * 4096);
+    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + koff, dst + BM * 128 + i * 4096);
   };
   auto dma_wait_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,6 +462,8 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.dtype_bf16 = a->dtype == DFW_BF16;
   p.gn_partial = a->gn_partial; p.gn_groups = a->gn_groups; p.gn_chunks = 0;
   p.gn_coef = a->gn_in_coef; p.gn_silu = a->gn_in_silu;
+  static const char* tapmajor = getenv("DFW_BIG_TAPMAJOR");   // A/B: tap-major K walk of the conv kernels
+  p.conv_chunk_major = (a->taps == 9 && !tapmajor) ? 1 : 0;
   if (p.splitk > p.nk) p.splitk = p.nk;
   plan_gemm(p, p.plan_bm, p.plan_bn);
   return 0;

@@ -165,10 +165,23 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
         const uint32_t off = ((a_pix[i] + (uint32_t)(iy * p.Wi + ix)) * (uint32_t)p.lda + coff) * (uint32_t)sizeof(T);
         dma16(ra, ok ? off : kOOB, dst + i * 8192);
       }
-      if (++cc == cpt) { cc = 0; ++tap; }
+    }
+    uint32_t koff = (uint32_t)ks * RB;
+    if constexpr (CONV) {
+      // K walk of a conv tile.  Channel-chunk-major (the nine taps of one 32-channel chunk back to back):
+      // the shifted re-reads of the input patch come one K-step after the first touch and hit the XCD's
+      // L2, where the tap-major walk (all chunks of a tap, then the next tap) re-read each byte Cin/32
+      // steps later, after 32 workgroups had pushed ~4 MB through that 4 MB L2.  Fewer bytes from beyond
+      // L2 is also the largest clock lever the guide lists for a power-limited MFMA loop (rule 28).
+      koff = (uint32_t)(tap * p.Cin + cc * BK) * (uint32_t)sizeof(T);
+      if (p.conv_chunk_major) {
+        if (++tap == 9) { tap = 0; ++cc; }
+      } else {
+        if (++cc == cpt) { cc = 0; ++tap; }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + (uint32_t)ks * RB, dst + BM * RB + i * 8192);
+    for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + koff, dst + BM * RB + i * 8192);
   };
   // ---- fragment read addresses within a stage (k-substep s: ^ (s<<5))
   uint32_t lds_ra[MB], lds_rw[NB];
