@@ -1,6 +1,7 @@
 // GroupNorm(+SiLU) and LayerNorm on NHWC / [rows][C] activations for gfx950.
 // HBM-bound: 16-byte vector access, fp32 statistics, deterministic reductions (no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace dfw {
 
@@ -16,6 +17,7 @@ struct GnP {
   int B, HW, C, groups, ldx, ldy, chunks, ppc;  // ppc = pixels per chunk
   float eps;
   int silu;
+  int nt;   // gn_apply: non-temporal stores
 };
 
 template <typename T>
@@ -146,7 +148,8 @@ __global__ void gn_apply_kernel(const GnP p) {
         const float v = f[i] * rs[i] + rh[i];
         f[i] = p.silu ? silu_f(v) : v;
       }
-      *(i32x4*)(yb + (size_t)(px + u * slots) * p.ldy * sizeof(T)) = pack8<T>(f);
+      if (p.nt) __builtin_nontemporal_store(pack8<T>(f), (i32x4*)(yb + (size_t)(px + u * slots) * p.ldy * sizeof(T)));
+      else *(i32x4*)(yb + (size_t)(px + u * slots) * p.ldy * sizeof(T)) = pack8<T>(f);
     }
   }
   for (; px < p1; px += slots) {
@@ -261,6 +264,11 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   p.mr = p.part + (size_t)a->B * chunks * a->groups * 2;
   p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.ldy = a->ldy;
   p.chunks = chunks; p.ppc = ppc; p.eps = a->eps; p.silu = a->silu;
+  // Non-temporal stores make this kernel 15-30 % faster in isolation (4.7 -> 5.5 TB/s) but the step no
+  // faster (47.2 vs 47.0 ms, same box): the consumer conv then misses L2 / Infinity Cache on its first
+  // touch.  Opt-in for callers whose consumer is not the next kernel.
+  static const char* nt = getenv("DFW_GN_NT");
+  p.nt = (nt && nt[0] == '1') ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds1 = (size_t)slots * a->C * 2 * sizeof(float);
   if (lds1 > 64 * 1024) return DFW_ESHAPE;
