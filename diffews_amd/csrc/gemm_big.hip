@@ -118,7 +118,6 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   int a_iy0[SA], a_ix0[SA];
   uint32_t a_pix[SA];
   uint32_t w_off[SW];
-  int tap = 0, cc = 0;
   const unsigned limH = p.ups ? 2 * p.Hi : p.Hi, limW = p.ups ? 2 * p.Wi : p.Wi;
   const int ush = p.ups ? 1 : 0;
   auto setup_loader = [&](const TileC& c) {
@@ -145,11 +144,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
       const int n = c.n0 + (i * 8 + wave) * RPI + lrow;
       w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
     }
-    tap = 0;
-    cc = 0;
   };
   auto issue = [&](int ks, int slot) {
     const uint32_t dst = lds0 + (uint32_t)slot * STAGE + (uint32_t)wave * 1024u;
+    // conv K walk: step ks of the tile -> (tap, channel chunk); derived from ks (scalar arithmetic), not
+    // carried as loop state (state captured by the two loop instantiations ended up in scratch, and its
+    // reload put an s_waitcnt vmcnt(0) -- a full drain of the DMA ring -- into every K-step)
+    int tap = 0, cc = 0;
+    if constexpr (CONV) {
+      if (p.conv_chunk_major) { cc = ks / 9; tap = ks - cc * 9; }
+      else { tap = ks / cpt; cc = ks - tap * cpt; }
+    }
     if constexpr (!CONV) {
 #pragma unroll
       for (int i = 0; i < SA; ++i) dma16(ra, a_off[i] + (uint32_t)ks * RB, dst + i * 8192);
@@ -174,11 +179,6 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
       // steps later, after 32 workgroups had pushed ~4 MB through that 4 MB L2.  Fewer bytes from beyond
       // L2 is also the largest clock lever the guide lists for a power-limited MFMA loop (rule 28).
       koff = (uint32_t)(tap * p.Cin + cc * BK) * (uint32_t)sizeof(T);
-      if (p.conv_chunk_major) {
-        if (++tap == 9) { tap = 0; ++cc; }
-      } else {
-        if (++cc == cpt) { cc = 0; ++tap; }
-      }
     }
 #pragma unroll
     for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + koff, dst + BM * RB + i * 8192);
@@ -387,6 +387,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
     // image as the 32x32 path (row r: 16-byte chunk c at ((c ^ (r & 7)) << 4)), so the statistics and the
     // whole-line stores below are shared logic
     auto epilogue6 = [&](const TileC& c, char* stg, int tile_id) {
+      // lane-derived indices are recomputed here, behind an opaque copy of the lane id: hoisted to kernel
+      // entry (LICM) they live across the K loop and spill at this kernel's 256-register budget
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
       float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
       for (int i = 0; i < MB6 / 2; ++i) {
@@ -496,6 +501,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
     int ti_next = 0;
     auto kloop = [&](auto G1) __attribute__((always_inline)) {
       constexpr bool g1 = decltype(G1)::value;
+#pragma unroll 1
       for (int k = 0; k < nks - (S - 1); ++k) {
         if constexpr (!g1) reads(rs);
         bar();
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
         rs = nxt(rs);
       }
       if (has_next) setup_loader(tile_coords(tile0 + (ti_next) * nxb));
-#pragma unroll
+#pragma unroll 1
       for (int j = 0; j < S - 1; ++j) {
         if constexpr (!g1) reads(rs);
         bar();
