@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffews_hip.so")
+LIB_PATH = os.environ.get("DFW_LIB") or os.path.join(_HERE, "libdiffews_hip.so")   # DFW_LIB: A/B another build
 
 BF16, F16 = 0, 1
 OUT_T, OUT_F32, OUT_NCHW_F32 = 0, 1, 2

@@ -100,7 +100,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   int a_iy0[SA], a_ix0[SA]; // conv
   uint32_t a_pix[SA];
   uint32_t w_off[SW];
-  int tap = 0, cc = 0;      // conv: tap / channel chunk of the K-step being loaded
   const unsigned limH = p.ups ? 2 * p.Hi : p.Hi, limW = p.ups ? 2 * p.Wi : p.Wi;
   const int ush = p.ups ? 1 : 0;
   auto setup_loader = [&](const TileC& c) {
@@ -127,15 +126,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       const int n = c.n0 + srow + 32 * i;
       w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
     }
-    if constexpr (CONV) {
-      if (p.conv_chunk_major) {
-        cc = ks0 / 9;
-        tap = ks0 - cc * 9;
-      } else {
-        tap = ks0 / p.cpt;
-        cc = ks0 - tap * p.cpt;
-      }
-    }
   };
 
   // fragment read addresses (k-substep s: ^ (s<<5)); the LDS image is [row][slot] with
@@ -160,6 +150,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   // issue the LDS-DMA of K-step ks into buffer `buf` (8 rows x 128 B per wave-instruction)
   auto issue_loads = [&](int ks, char* buf) {
     char* dst = buf + wave_lds;
+    // conv K walk: (tap, 64-channel chunk) derived from the K-step index -- carried as loop state they
+    // were captured by reference and lived in scratch memory (a scratch load per K-step)
+    int tap = 0, cc = 0;
+    if constexpr (CONV) {
+      if (p.conv_chunk_major) { cc = ks / 9; tap = ks - cc * 9; }
+      else { tap = ks / p.cpt; cc = ks - tap * p.cpt; }
+    }
     if constexpr (!CONV) {
 #pragma unroll
       for (int i = 0; i < SA; ++i) dma16(ra, a_off[i] + (uint32_t)ks * 128u, dst + i * 4096);
@@ -182,11 +179,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       // of the input patch hit L2 one step after the first touch (see gemm_big.hip); split-K ranges are
       // contiguous runs of this walk
       koff = (uint32_t)(tap * p.Cin + cc * 64) * (uint32_t)sizeof(T);
-      if (p.conv_chunk_major) {
-        if (++tap == 9) { tap = 0; ++cc; }
-      } else {
-        if (++cc == p.cpt) { cc = 0; ++tap; }
-      }
     }
 #pragma unroll
     for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] + koff, dst + BM * 128 + i * 4096);
