@@ -18,6 +18,7 @@ struct GnP {
   float eps;
   int silu;
   int nt;   // gn_apply: non-temporal stores
+  int rev;  // statistics / apply: walk images and pixel chunks back to front
 };
 
 template <typename T>
@@ -26,7 +27,11 @@ __global__ void gn_stats_kernel(const GnP p) {
   float* ls = (float*)smem_n;  // [slots][C][2]
   const int tpp = p.C >> 3, slots = blockDim.x / tpp;
   const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
-  const int b = blockIdx.y, chunk = blockIdx.x;
+  // walk the tensor from its END: the producer (a conv that wrote it front to back) has just left its
+  // tail in L2 / Infinity Cache, and this kernel's own output then ends at the front, where the next conv
+  // starts reading
+  const int b = p.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int chunk = p.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int p0 = chunk * p.ppc, p1 = min(p.HW, p0 + p.ppc);
   float s[8], ss[8];
 #pragma unroll
@@ -116,11 +121,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
 // Apply: thread = fixed 8 channels (scale/shift in registers), streams its pixel range.
 template <typename T>
 __global__ void gn_apply_kernel(const GnP p) {
-  const int b = blockIdx.y;
+  const int b = p.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int chunk = p.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int cpg = p.C / p.groups;
   const int tpp = p.C >> 3, slots = blockDim.x / tpp;
   const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
-  const int p0 = blockIdx.x * p.ppc, p1 = min(p.HW, p0 + p.ppc);
+  const int p0 = chunk * p.ppc, p1 = min(p.HW, p0 + p.ppc);
   float rs[8], rh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -267,6 +273,8 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   // Non-temporal stores make this kernel 15-30 % faster in isolation (4.7 -> 5.5 TB/s) but the step no
   // faster (47.2 vs 47.0 ms, same box): the consumer conv then misses L2 / Infinity Cache on its first
   // touch.  Opt-in for callers whose consumer is not the next kernel.
+  static const char* fwd = getenv("DFW_GN_FWD");   // A/B: front-to-back walk
+  p.rev = fwd ? 0 : 1;
   static const char* nt = getenv("DFW_GN_NT");
   p.nt = (nt && nt[0] == '1') ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
