@@ -178,6 +178,27 @@ def unpack3x3(wp, Cin):
     return wp.float().view(wp.shape[0], 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(12, 128, 256, 256), (3, 512, 128, 128), (12, 64, 512, 512)])
+def test_conv_ring_kernels_race_screen(ops, B, H, Cin, Cout):
+    """The ping-pong conv kernels keep three LDS-DMA stages in flight across two barriers per K-step; an
+    ordering slip there shows up as run-to-run differences long before it fails a tolerance.  Same problem
+    launched repeatedly with unrelated work in between: outputs and fused statistics must be bit-identical."""
+    from diffews_amd.packing import pack_conv3x3
+    dtype = torch.bfloat16
+    x = rnd((B, H, H, Cin), dtype, 1).cuda()
+    w = pack_conv3x3(rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)).cuda()
+    bias = torch.randn(Cout).cuda()
+    res = rnd((B, H, H, Cout), dtype, 3).cuda()
+    junk = torch.randn(2048, 2048, device="cuda")
+    first = ops.conv3x3(x, w, Cout, bias=bias, residual=res, gn_groups=32)
+    st0 = first._gn_stats[0].clone()
+    for it in range(12):
+        if it % 3 == 0:
+            junk = junk @ junk * 1e-4
+        y = ops.conv3x3(x, w, Cout, bias=bias, residual=res, gn_groups=32)
+        assert torch.equal(y, first) and torch.equal(y._gn_stats[0], st0), it
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_big_tiles(ops, dtype):
     from diffews_amd.packing import pack_geglu
