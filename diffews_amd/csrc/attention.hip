@@ -31,7 +31,7 @@ namespace dfw {
 struct FsaP {
   const char* q; const char* k; const char* v; const char* kb; const char* vb; char* out;
   uint32_t q_bytes, k_bytes, v_bytes, kb_bytes, vb_bytes;
-  int batch, heads, n_q, n_kv, n_bank, nshot, n_plain;
+  int batch, heads, n_q, n_kv, n_bank, nshot, n_plain, xcd_remap;
   int ldq, ldk, ldv, ldkb, ldvb, ldo;
   long long q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs;
   float c;  // scale * log2(e)
@@ -308,9 +308,29 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   // Longest work first: images [n_plain, batch) also walk their episode's bank (the query images of a
   // lock-step [support ; query] launch) and sit at the END of the batch, so the z walk is reversed --
   // their workgroups are dispatched first and the short support-image ones fill in behind them.
-  const int head = blockIdx.y, b = (int)gridDim.z - 1 - (int)blockIdx.z;
+  // XCD-aware placement: workgroups are dispatched round-robin over the 8 XCDs in launch order, so with
+  // the plain (x, head, image) grid the 16 query blocks that stream the SAME K/V of one (image, head) land
+  // on 8 different L2s and every L2 fetches that K/V from beyond it.  When (heads * images) % 8 == 0 the
+  // launch-order index is re-read as (XCD c, k-th workgroup on it) -> pair c + 8*(k / X), query block
+  // k % X: all query blocks of a pair share one XCD's L2, pairs still go out longest first.
+  int head, b, qblk;
+  {
+    const int X = (int)gridDim.x, H = (int)gridDim.y, P = H * (int)gridDim.z;
+    const int v = (int)blockIdx.x + X * ((int)blockIdx.y + H * (int)blockIdx.z);
+    if ((P & 7) == 0 && p.xcd_remap) {
+      const int c = v & 7, k = v >> 3;
+      const int pr = c + 8 * (k / X);
+      qblk = k - (k / X) * X;
+      head = pr % H;
+      b = (int)gridDim.z - 1 - pr / H;
+    } else {
+      qblk = (int)blockIdx.x;
+      head = (int)blockIdx.y;
+      b = (int)gridDim.z - 1 - (int)blockIdx.z;
+    }
+  }
   const int bank_b = b - p.n_plain;          // episode index into the bank (< 0: own keys only)
-  const int q0 = blockIdx.x * (NW * 32 * QB) + wave * (32 * QB);
+  const int q0 = qblk * (NW * 32 * QB) + wave * (32 * QB);
   const uint32_t lds0 = lds_addr(smem);
 
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q, p.q_bytes);
@@ -674,6 +694,8 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   p.kb_bytes = (uint32_t)(kbe * 2); p.vb_bytes = (uint32_t)(vbe * 2);
   p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_kv = a->n_kv;
   p.n_bank = a->n_bank; p.nshot = a->nshot; p.n_plain = a->n_plain;
+  static const char* noremap = getenv("DFW_FSA_NOREMAP");   // A/B switch
+  p.xcd_remap = noremap ? 0 : 1;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldkb = a->ldkb; p.ldvb = a->ldvb; p.ldo = a->ldo;
   p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.kb_bs = a->kb_bs; p.vb_bs = a->vb_bs; p.o_bs = a->o_bs;
   p.c = a->scale * 1.4426950408889634f;
