@@ -184,3 +184,45 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt):
             del ref
     finally:
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+def test_fullsize_other_resolutions_against_oracle_on_device(hip_lib):
+    """Resolutions whose latent sizes do not fit the 16x16-pixel conv tiles or the 256-row attention blocks
+    (384x384 -> 48x48 ... 6x6, 320x512 2-shot; scratch/other_res.py also covers 448, 768, 64): the ragged
+    paths of every kernel, SD-2.1 + SD VAE in fp16, against the fp32 oracle run on the device."""
+    from diffews_amd import config, weights
+    from diffews_amd.pipeline import MarigoldPipelineRGBLatentNoise
+    from diffews_amd.scheduler import DDIMSchedulerCustomized
+    from diffews_amd.unet import MyUNet2DConditionModel
+    from diffews_amd.vae import AutoencoderKL
+    from oracle import pipeline as OP
+    from oracle.unet import OracleUNet
+    from oracle.vae import OracleVAE
+    dt = torch.float16
+    ucfg, vcfg = config.get("sd21_unet"), config.get("sd_vae")
+    kwf = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
+    usd = weights.synthetic_unet_state_dict(ucfg, round_to=dt)
+    vsd = weights.synthetic_vae_state_dict(vcfg, round_to=dt)
+    te = weights.synthetic_text_embed(ucfg).to(dt).float()
+    prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        ou = OracleUNet(**kwf(ucfg)); ou.load_state_dict(usd); ou = ou.eval().cuda()
+        ov = OracleVAE(**kwf(vcfg)); ov.load_state_dict(vsd); ov = ov.eval().cuda()
+        pipe = MarigoldPipelineRGBLatentNoise(
+            MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt), AutoencoderKL(vcfg, vsd, torch_dtype=dt),
+            DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
+        g = torch.Generator().manual_seed(5)
+        for H, W, b, s in ((384, 384, 1, 1), (320, 512, 1, 2)):
+            sup = (torch.rand(b * s, 3, H, W, generator=g) * 2 - 1).cuda()
+            qry = (torch.rand(b, 3, H, W, generator=g) * 2 - 1).cuda()
+            m = torch.zeros(b * s, 1, H, W)
+            m[:, :, H // 4:3 * H // 4, W // 4:3 * W // 4] = 1
+            msk = (m.repeat(1, 3, 1, 1) * 2 - 1).cuda()
+            with torch.no_grad():
+                ref = OP.single_infer(ou, ov, sup, qry, msk, te.cuda())
+            r = pipe.run_episodes(sup, qry, msk)
+            assert rel(r["z0"], ref["z0"]) < 4e-3, (H, W, rel(r["z0"], ref["z0"]))
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
