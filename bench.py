@@ -52,9 +52,10 @@ def build_pipeline(dtype, tiny=False):
     return pipe, (ucfg, usd, vcfg, vsd, te)
 
 
-def cpu_baseline(model_blobs, res, nshot, budget_s=25.0):
+def cpu_baseline(model_blobs, res, nshot, budget_s=20.0):
     """fp32 CPU oracle (oracle/, the restatement of the reference's diffusers graph) on a bounded
-    sample of the same workload: single episodes at the bench resolution, >= 1 timed episode."""
+    sample: single episodes of the bench workload's shape (>= 1 timed episode, `value`), and BASELINE.json
+    configs[0] -- one 256x256 1-shot episode, fp32, 1 denoise step -- timed >= 3 times beside it."""
     from oracle import pipeline as op
     from oracle.unet import OracleUNet
     from oracle.vae import OracleVAE
@@ -70,18 +71,25 @@ def cpu_baseline(model_blobs, res, nshot, budget_s=25.0):
     kw = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
     ou = OracleUNet(**kw(ucfg)); ou.load_state_dict(usd); ou.eval()
     ov = OracleVAE(**kw(vcfg)); ov.load_state_dict(vsd); ov.eval()
-    bt = episodes.make_episode_batch(1, nshot, res, seed=7)
-    n, t_total = 0, 0.0
-    while True:
-        t0 = time.time()
-        op.single_infer(ou, ov, bt["support_imgs"], bt["query_img"], bt["support_masks"], te)
-        dt = time.time() - t0
-        n += 1
-        t_total += dt
-        if t_total + dt > budget_s or n >= 3:
-            break
-    return dict(value=n / t_total, unit="episodes/s", cores=cores, kind="port",
-                sample=f"{n} episode(s) {res}x{res} {nshot}-shot fp32, oracle/ on {cores} host threads, {t_total:.1f}s")
+
+    def timed(r, s, min_n, max_n, budget):
+        bt = episodes.make_episode_batch(1, s, r, seed=7)
+        op.single_infer(ou, ov, bt["support_imgs"], bt["query_img"], bt["support_masks"], te) if r <= 256 else None  # warm-up (cheap sizes only)
+        ts = []
+        while True:
+            t0 = time.time()
+            op.single_infer(ou, ov, bt["support_imgs"], bt["query_img"], bt["support_masks"], te)
+            ts.append(time.time() - t0)
+            if len(ts) >= max_n or (len(ts) >= min_n and sum(ts) + ts[-1] > budget):
+                break
+        return ts
+    t256 = timed(256, 1, 3, 5, 8.0)
+    tb = timed(res, nshot, 1, 3, budget_s)
+    med = sorted(t256)[len(t256) // 2]
+    return dict(value=len(tb) / sum(tb), unit="episodes/s", cores=cores, kind="port",
+                sample=f"{len(tb)} episode(s) {res}x{res} {nshot}-shot fp32, oracle/ on {cores} host threads, {sum(tb):.1f}s",
+                configs0_256x256_1shot=dict(value=round(1.0 / med, 4), unit="episodes/s", episodes=len(t256),
+                                            median_s=round(med, 3), note="BASELINE.json configs[0]: fp32, 1 denoise step, after 1 warm-up"))
 
 
 def roofline_pass(step):
@@ -112,6 +120,46 @@ def roofline_pass(step):
     return agg
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no RANK in the environment: start the N ranks as CHILD processes
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line
+    (the children inherit stdout) and exit with their code.  Nothing here touches the GPU; the parent never
+    re-execs itself."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if ndev < n and not os.environ.get("DFW_ONE_DEVICE"):
+        log(f"[bench] --gpus {n} requested but this node shows {ndev} GPU(s): refusing to report a smaller run")
+        return 2
+    from diffews_amd import build
+    build.build()                              # before any rank starts (no hipcc race between ranks)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("[bench] spawning: " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def latest_pmc_summary():
+    """Newest profiles/rNN_pmc_traffic.json (by round number): per-kernel HBM bytes and MFMA utilisation from
+    the separate rocprofv3 --pmc passes of that round (profiles/run_pmc.sh)."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, {}
+    with open(best[1]) as f:
+        return os.path.basename(best[1]), json.load(f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,16 +175,25 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args.gpus)            # before ANY torch.cuda / HIP call in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    if world != args.gpus:
+        raise SystemExit(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch as `python bench.py --gpus N` "
+                         f"(spawns its own ranks) or under torchrun with --nproc-per-node equal to --gpus")
+    from diffews_amd import build, episodes
+    if rank == 0:
+        build.build()   # no-op when the in-tree .so is current; BEFORE the GPU is touched (hipcc children)
     import torch.distributed as dist
     # DFW_DIST_BACKEND=gloo + DFW_ONE_DEVICE=1: rehearse the N>1 control flow with every rank on
     # cuda:0 of a one-GPU box (RCCL refuses two ranks on one device); never used for a bench line.
     backend = os.environ.get("DFW_DIST_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("DFW_ONE_DEVICE") else local_rank
+    ndev = torch.cuda.device_count()
+    if dev_index >= ndev:
+        raise SystemExit(f"[bench] rank {rank} needs cuda:{dev_index} but this node shows {ndev} GPU(s)")
     torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -145,13 +202,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        dist.barrier()          # the other ranks wait here for rank 0's build check
+        log(f"[bench] rank {rank}/{dist.get_world_size()} on cuda:{dev_index}, backend {dist.get_backend()}")
 
-    from diffews_amd import build, episodes
     from diffews_amd.metrics import AverageMeter, fold_class_ids
-    if rank == 0:
-        build.build()   # no-op when the in-tree .so is current; never raced by the other ranks
-    if world > 1:
-        dist.barrier()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, blobs = build_pipeline(dtype, tiny=args.tiny)
 
@@ -160,31 +214,29 @@ def main():
     cls = episodes.episode_class_ids(list(range(rank * b, rank * b + b))).cuda()
     meter = AverageMeter("coco", fold_class_ids("coco", 0), device="cuda")
     out = {}
+    use_graph = not args.no_graph
 
-    def step():
-        r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"])
+    def step(captured=None):
+        # the product's own step: one HIP-graph replay owned by the pipeline (run_episodes(captured=True)),
+        # then the meter update (one small kernel)
+        r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"],
+                              captured=use_graph if captured is None else captured)
         meter.update_from_counts(r["counts"], cls)
         out["z0"] = r["z0"]
 
-    # warmup (eager), then capture the whole step in one HIP graph
+    # warm-up: eager steps, then (graph mode) the capture + replays; afterwards the episode tensors ARE the
+    # graph's static input buffers, so a step starts with its inputs resident in HBM and copies nothing
     for _ in range(max(1, args.warmup)):
-        step()
+        step(captured=False)
     torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        torch.cuda.synchronize()
+    if use_graph:
+        step()
+        stat = pipe.episode_input_buffers(b, s, res)
+        bt = dict(support_imgs=stat["support_imgs"], query_img=stat["query_img"],
+                  support_masks=stat["support_masks"], query_mask=stat["query_gt"])
         for _ in range(args.warmup):
-            graph.replay()
-    run = graph.replay if graph is not None else step
+            step()
+    run = step
 
     meter.intersection_buf.zero_()
     meter.union_buf.zero_()
@@ -214,9 +266,19 @@ def main():
     if not finite:
         raise SystemExit("non-finite latents: invalid run")
 
+    eager_ms = None
+    if rank == 0 and use_graph:                  # the same step launched kernel by kernel (host-bound): recorded, not `value`
+        step(captured=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(captured=False)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t1) / 3 * 1e3
+        log(f"[bench] eager (no graph) {eager_ms:.2f} ms/step vs graph {elapsed / args.steps * 1e3:.2f} ms/step")
     roof = None
     if rank == 0 and not args.no_roofline:
-        agg = roofline_pass(step)
+        agg = roofline_pass(lambda: step(captured=False))
         tot_t = sum(v[2] for v in agg.values())
         for name, (n, fl, t) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
             log(f"[roofline] {name:40s} launches {n:4d}  {t * 1e3:8.3f} ms  {fl / t / 1e12:7.1f} TFLOP/s  "
@@ -226,17 +288,18 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         n, fl, t = dom[1]
         ach = fl / t / 1e12
-        # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE,
-        # WRITE_SIZE; they cannot share a pass with each other or with timing) summarised by
-        # profiles/summarize_pmc.py with the gfx950 correction (2*FETCH_SIZE + WRITE_SIZE) KiB.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = round(json.load(f)[dom[0]]["hbm_bytes_per_launch"])
-        except Exception:
-            pass
+        # HBM bytes per launch and MFMA-pipe utilisation of that kernel come from separate rocprofv3 --pmc
+        # passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE cannot share a pass with
+        # each other or with timing) summarised by profiles/summarize_pmc.py, gfx950 correction
+        # (2*FETCH_SIZE + WRITE_SIZE) KiB; the newest round's file is used and named in the line.
+        pmc_name, pmc = latest_pmc_summary()
+        traffic = mfma_util = None
+        if dom[0] in pmc:
+            traffic = round(pmc[dom[0]]["hbm_bytes_per_launch"])
+            mfma_util = pmc[dom[0]].get("mfma_util")
         roof = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic, launches_per_step=n,
+                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic, mfma_util=mfma_util,
+                    pmc_source=pmc_name, launches_per_step=n,
                     avg_launch_us=round(t / n * 1e6, 2), flops_per_launch=fl / n,
                     gemm_time_share_of_step=round(tot_t / (elapsed / args.steps), 3))
         if attn is not None:
@@ -246,7 +309,8 @@ def main():
             roof["attention"] = dict(kernel="fsa_ring_kernel", achieved=round(afl / at / 1e12, 2),
                                      peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                      frac=round(afl / at / 1e12 / MFMA_PEAK_TFLOPS, 4), launches_per_step=an,
-                                     ms_per_step=round(at * 1e3, 3))
+                                     ms_per_step=round(at * 1e3, 3),
+                                     mfma_util=pmc.get("fsa_ring_kernel", {}).get("mfma_util"))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -266,7 +330,9 @@ def main():
                                    f"({'BASELINE.json configs[1]' if (res, s, b) == (512, 1, 4) else 'non-default configuration'})"
                                    f"{' TINY-DEBUG' if args.tiny else ''}",
                        "episodes_per_gpu_per_step": b, "nshot": s, "resolution": res,
-                       "parallelism": f"episode-sharded x{n_gpus}", "hip_graph": graph is not None},
+                       "parallelism": f"episode-sharded x{n_gpus}", "hip_graph": use_graph,
+                       "graph_owner": "pipeline.run_episodes(captured=True)" if use_graph else None,
+                       "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
@@ -275,4 +341,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

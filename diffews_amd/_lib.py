@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DFW_LIB") or os.path.join(_HERE, "libdiffews_hip.so")
 
 BF16, F16 = 0, 1
 OUT_T, OUT_F32, OUT_NCHW_F32 = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_CLAMP1 = 0, 1, 2
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -58,7 +58,8 @@ class ConvSmallArgs(C.Structure):
     _fields_ = [("x", _vp), ("W", _vp), ("bias", _vp), ("y", _vp),
                 ("B", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("Cout", _i32), ("taps", _i32), ("ldy", _i32),
                 ("in_scale", _f32), ("out_scale", _f32), ("out_mode", _i32), ("dtype", _i32),
-                ("gn_partial", _vp), ("gn_groups", _i32)]
+                ("gn_partial", _vp), ("gn_groups", _i32), ("y_bstride", _i64),
+                ("x1", _vp), ("x2", _vp), ("b0", _i32), ("b1", _i32)]
 
 
 class ImageArgs(C.Structure):
@@ -89,6 +90,8 @@ SYMBOLS = {
     "dfw_concat_channels": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dfw_timestep_embedding": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_seg_postprocess": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "dfw_seg_postprocess_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "dfw_meter_update": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "dfw_resample_ksize": (_i32, [_i32, _i32]),
     "dfw_resample_coeffs": (_i32, [_i32, _i32, _vp, _vp]),
     "dfw_image_to_tensor": (_i32, [C.POINTER(ImageArgs), _vp]),

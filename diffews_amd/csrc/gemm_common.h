@@ -56,6 +56,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
   for (int i = 0; i < 4; ++i) {
     v[i] *= p.out_scale;
     if (p.act == DFW_ACT_SILU) v[i] = silu_f(v[i]);
+    else if (p.act == DFW_ACT_CLAMP1) v[i] = fminf(fmaxf(v[i], -1.0f), 1.0f);
   }
   if (p.out_mode == DFW_OUT_T && vec) {
     *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
@@ -117,6 +118,7 @@ __device__ __forceinline__ void epi_block(const GemmP& p, char* Cb, int m, int i
       for (int e = 0; e < 4; ++e) {
         v[e] = (a[j][4 * g + e] + add[j][g][e] + r[e]) * p.out_scale;
         if (!SLIM && p.act == DFW_ACT_SILU) v[e] = silu_f(v[e]);
+        else if (!SLIM && p.act == DFW_ACT_CLAMP1) v[e] = fminf(fmaxf(v[e], -1.0f), 1.0f);
       }
       if (SLIM || p.out_mode == DFW_OUT_T) {
         *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);

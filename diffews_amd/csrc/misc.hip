@@ -12,7 +12,17 @@ struct CsP {
   float in_scale, out_scale;
   int iters;   // conv_small8w: pixel groups per thread
   float* gn_partial; int gn_groups, gn_chunks;   // fused GroupNorm partial sums of the NHWC output (optional)
+  long long ybs;   // NCHW fp32 output: floats between images
+  const float* x1; const float* x2; int b0, b1;   // images [b0, b1) come from x1, [b1, B) from x2 (x1 == nullptr: all from x)
 };
+
+// first input plane of image b (the batch may be spread over up to three buffers)
+__device__ __forceinline__ const float* cs_image(const CsP& p, int b) {
+  const size_t per = (size_t)p.Cin * p.H * p.Wd;
+  if (p.x1 == nullptr || b < p.b0) return p.x + (size_t)b * per;
+  if (b < p.b1) return p.x1 + (size_t)(b - p.b0) * per;
+  return p.x2 + (size_t)(b - p.b1) * per;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_small_kernel(const CsP p) {
@@ -40,7 +50,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const CsP p) {
     const int iy = y + ky - pad, ix = x + kx - pad;
     if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.Wd) continue;
     for (int c = 0; c < p.Cin; ++c) {
-      const float v = p.x[((size_t)(b * p.Cin + c) * p.H + iy) * p.Wd + ix] * p.in_scale;
+      const float v = cs_image(p, b)[((size_t)c * p.H + iy) * p.Wd + ix] * p.in_scale;
       const float* w = ws + (t * p.Cin + c) * 8;
 #pragma unroll
       for (int o = 0; o < 8; ++o) acc[o] += v * w[o];
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const CsP p) {
   } else {
 #pragma unroll
     for (int o = 0; o < 8; ++o)
-      if (co0 + o < p.Cout) ((float*)p.y)[((size_t)b * p.Cout + co0 + o) * HW + rem] = acc[o];
+      if (co0 + o < p.Cout) ((float*)p.y)[(size_t)b * p.ybs + (size_t)(co0 + o) * HW + rem] = acc[o];
   }
 }
 
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_small4_kernel(const CsP p) {
     const int iy = y + ky - pad;
     if ((unsigned)iy >= (unsigned)p.H) continue;
     for (int c = 0; c < p.Cin; ++c) {
-      const float* row = p.x + ((size_t)(b * p.Cin + c) * p.H + iy) * p.Wd;
+      const float* row = cs_image(p, b) + ((size_t)c * p.H + iy) * p.Wd;
       const f32x4 mid = *(const f32x4*)(row + x0);
       float in[6];
       in[0] = (pad && x0 > 0) ? row[x0 - 1] * p.in_scale : 0.f;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_small4_kernel(const CsP p) {
         f32x4 v;
 #pragma unroll
         for (int px = 0; px < 4; ++px) v[px] = (acc[px][o] + bs[o]) * p.out_scale;
-        *(f32x4*)((float*)p.y + ((size_t)b * p.Cout + co0 + o) * HW + pix) = v;
+        *(f32x4*)((float*)p.y + (size_t)b * p.ybs + (size_t)(co0 + o) * HW + pix) = v;
       }
   }
 }
@@ -167,6 +177,7 @@ __global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
     if (q >= nq) return;
     const int b = (int)(q / (p.H * W8)), rem = (int)(q - (long long)b * p.H * W8);
     const int y = rem / W8, x0 = (rem - y * W8) * 8;
+    const float* xim = cs_image(p, b);
     f32x2 acc[8][4];                       // [pixel][channel pair]: packed fp32 FMAs
     // (fused GroupNorm statistics: host guarantees every thread is live in every iteration)
 #pragma unroll
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
       const int iy = y + ky - PAD;
       if ((unsigned)iy >= (unsigned)p.H) continue;
       for (int c = 0; c < p.Cin; ++c) {
-        const float* row = p.x + ((size_t)(b * p.Cin + c) * p.H + iy) * p.Wd;
+        const float* row = xim + ((size_t)c * p.H + iy) * p.Wd;
         const f32x4 m0 = *(const f32x4*)(row + x0), m1 = *(const f32x4*)(row + x0 + 4);
         float in[10];
         in[0] = (PAD && x0 > 0) ? row[x0 - 1] * p.in_scale : 0.f;
@@ -431,12 +442,19 @@ __global__ __launch_bounds__(256) void seg_u8_kernel(const float* x, uint8_t* u8
 // pred = mean_c(u8 / 255) > thr, same fp32 expressions as the reference's to_tensor + mean
 // (byte / 255.0f through a per-block table: 256 IEEE divisions per block instead of 3 per pixel).
 __global__ __launch_bounds__(256) void seg_count_kernel(const uint8_t* u8, const uint8_t* gt, const uint32_t* mx,
-                                                        long long* counts, int HW, float r_thr) {
+                                                        long long* counts, int HW, float r_thr, float fixed_thr,
+                                                        int batch_max) {
   __shared__ float lut[256];
   lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
   __syncthreads();
   const int b = blockIdx.y;
-  const float thr = ((float)mx[b] / 255.0f) * r_thr;
+  // r_thr > 0: dynamic threshold max * r_threshold (main_oss.py:129-132) with the max taken over this image
+  // or (batch_max) over the whole batch tensor, as `pred_mask.max()` literally does; else the fixed
+  // `--threshold` (main_oss.py:134-135)
+  uint32_t m = mx[b];
+  if (batch_max)
+    for (int i = 0; i < (int)gridDim.y; ++i) m = max(m, mx[i]);
+  const float thr = r_thr > 0.f ? ((float)m / 255.0f) * r_thr : fixed_thr;
   // inter0, inter1, pred0, pred1, gt0, gt1
   unsigned c[6] = {0, 0, 0, 0, 0, 0};
   const uint8_t* ub = u8 + (size_t)b * 3 * HW;
@@ -487,6 +505,17 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const uint8_t* u8, const
   }
 }
 
+__global__ void meter_update_kernel(const long long* counts, const long long* cls, unsigned long long* ib,
+                                    unsigned long long* ub, int B, int nclass) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * 2) return;
+  const int b = e >> 1, k = e & 1;
+  const long long c = cls[b];
+  if (c < 0 || c >= nclass) return;
+  atomicAdd(ib + (size_t)k * nclass + c, (unsigned long long)counts[b * 4 + k]);
+  atomicAdd(ub + (size_t)k * nclass + c, (unsigned long long)counts[b * 4 + 2 + k]);
+}
+
 }  // namespace dfw
 
 using namespace dfw;
@@ -523,6 +552,14 @@ extern "C" int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream)
   p.x = a->x; p.W = a->W; p.bias = a->bias; p.y = (char*)a->y;
   p.B = a->B; p.Cin = a->Cin; p.H = a->H; p.Wd = a->Wd; p.Cout = a->Cout; p.taps = a->taps;
   p.ldy = a->ldy; p.out_mode = a->out_mode; p.in_scale = a->in_scale; p.out_scale = a->out_scale;
+  p.x1 = a->x1; p.x2 = a->x2; p.b0 = a->b0; p.b1 = a->b1;
+  if (a->x1) {
+    if (a->b0 <= 0 || a->b1 < a->b0 || a->b1 > a->B || (a->b1 < a->B && !a->x2)) return DFW_EINVAL;
+    if (((uintptr_t)a->x1 % 16) != 0 || (a->x2 && ((uintptr_t)a->x2 % 16) != 0)) return DFW_ESHAPE;
+  }
+  p.ybs = a->y_bstride > 0 ? a->y_bstride : (long long)a->Cout * a->H * a->Wd;
+  if (a->out_mode == DFW_OUT_NCHW_F32 && (p.ybs < (long long)a->Cout * a->H * a->Wd || (p.ybs & 3) || ((uintptr_t)a->y & 15)))
+    return DFW_ESHAPE;
   const long long pix = (long long)a->B * a->H * a->Wd;
   hipStream_t st = (hipStream_t)stream;
   p.gn_partial = nullptr; p.gn_groups = 0; p.gn_chunks = 0;
@@ -631,8 +668,17 @@ extern "C" int dfw_timestep_embedding(const float* timesteps, void* out, int32_t
 extern "C" int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_t* gt, int64_t* counts,
                                    uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
                                    dfw_stream_t stream) {
+  return dfw_seg_postprocess_ex(x, seg_u8, gt, counts, scratch, B, H, Wd, r_threshold, 0.0f, 0, stream);
+}
+
+extern "C" int dfw_seg_postprocess_ex(const float* x, uint8_t* seg_u8, const uint8_t* gt, int64_t* counts,
+                                      uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
+                                      float threshold, int32_t batch_max, dfw_stream_t stream) {
   if (!x || !seg_u8 || !scratch || B <= 0 || H <= 0 || Wd <= 0) return DFW_EINVAL;
   if (gt && !counts) return DFW_EINVAL;
+  // the reference leaves the 3-channel mask un-thresholded when both flags are <= 0 and then fails its
+  // shape assert (main_oss.py:137): reject that here instead of counting something undefined
+  if (gt && !(r_threshold > 0.f) && !(threshold > 0.f)) return DFW_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int HW = H * Wd, per_img = 3 * HW;
   hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * sizeof(uint32_t), st);
@@ -649,14 +695,24 @@ extern "C" int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_
     if (cx > 64) cx = 64;
     if (cx < 1) cx = 1;
     hipLaunchKernelGGL(seg_count_kernel, dim3(cx, B), dim3(256), 0, st, (const uint8_t*)seg_u8, gt,
-                       (const uint32_t*)scratch, (long long*)counts, HW, r_threshold);
+                       (const uint32_t*)scratch, (long long*)counts, HW, r_threshold, threshold, batch_max ? 1 : 0);
     DFW_CHECK_LAUNCH();
   }
   return 0;
 }
 
+extern "C" int dfw_meter_update(const int64_t* counts, const int64_t* class_id, int64_t* inter_buf, int64_t* union_buf,
+                                int32_t B, int32_t nclass, dfw_stream_t stream) {
+  if (!counts || !class_id || !inter_buf || !union_buf || B <= 0 || nclass <= 0) return DFW_EINVAL;
+  hipLaunchKernelGGL(meter_update_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                     (const long long*)counts, (const long long*)class_id, (unsigned long long*)inter_buf,
+                     (unsigned long long*)union_buf, B, nclass);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
-extern "C" int dfw_version(void) { return 100; }
+extern "C" int dfw_version(void) { return 101; }
 
 extern "C" const char* dfw_error_string(int code) {
   switch (code) {

@@ -19,7 +19,8 @@ def episode_batches(indices, batch):
 
 @torch.no_grad()
 def test_diffusion(pipe, n_episodes, nshot=1, res=512, batch=1, benchmark="coco", fold=0, r_threshold=0.25,
-                   rank=0, world_size=1, make_batch=None, device=None, episodes=None):
+                   rank=0, world_size=1, make_batch=None, device=None, episodes=None, threshold=0.0,
+                   batch_max=False, captured=True):
     """Run `n_episodes` episodes sharded over `world_size` ranks; returns (miou, fb_iou, meter).
     Sources, first match wins:
       episodes   -- indexable of HOST episodes (decoded PIL images / uint8 arrays + class-id masks, the
@@ -27,7 +28,10 @@ def test_diffusion(pipe, n_episodes, nshot=1, res=512, batch=1, benchmark="coco"
                     GPU input pipeline (input_pipeline.EpisodeLoader: resize / normalise / mask kernels on a
                     side stream, prefetched);
       make_batch -- make_batch(indices) returns device tensors (dict of episodes.make_episode_batch + 'class_id');
-      otherwise  -- synthetic episodes (episodes.make_episode_batch)."""
+      otherwise  -- synthetic episodes (episodes.make_episode_batch).
+    captured: every step is one replay of the pipeline-owned HIP graph (pipeline.run_episodes(captured=True));
+    the per-step results are consumed (meter update on the same stream) before the next replay overwrites them.
+    r_threshold / threshold / batch_max: the launcher's thresholding flags (main_oss.py:128-135)."""
     device = device or pipe.device
     meter = AverageMeter(benchmark, fold_class_ids(benchmark, fold), device=device)
     mine = ep.shard(n_episodes, rank, world_size)
@@ -36,7 +40,7 @@ def test_diffusion(pipe, n_episodes, nshot=1, res=512, batch=1, benchmark="coco"
         loader = EpisodeLoader((episodes[i] for i in mine), res, batch, nshot, device=device)
         for bt in loader:
             r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"],
-                                  r_threshold=r_threshold)
+                                  r_threshold=r_threshold, threshold=threshold, batch_max=batch_max, captured=captured)
             meter.update_from_counts(r["counts"], bt["class_id"].to(device))
         meter.all_reduce()
         miou, fb_iou, _ = meter.compute_iou()
@@ -49,7 +53,7 @@ def test_diffusion(pipe, n_episodes, nshot=1, res=512, batch=1, benchmark="coco"
             bt = ep.make_episode_batch(len(idx), nshot, res, seed=1000 + idx[0], device=device)
             cls = ep.episode_class_ids(idx, benchmark, fold)
         r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"],
-                              r_threshold=r_threshold)
+                              r_threshold=r_threshold, threshold=threshold, batch_max=batch_max, captured=captured)
         meter.update_from_counts(r["counts"], cls.to(device))
     meter.all_reduce()
     miou, fb_iou, _ = meter.compute_iou()

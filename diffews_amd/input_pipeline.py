@@ -181,7 +181,8 @@ class EpisodeLoader:
                      qry=torch.empty(nb, 3, S, S, dtype=torch.float32, device=dev),
                      smask=torch.empty(nb * self.s, 3, S, S, dtype=torch.float32, device=dev),
                      qmask=torch.empty(nb, S, S, dtype=torch.uint8, device=dev),
-                     event=torch.cuda.Event(), release=torch.cuda.Event(), released=False)
+                     event=torch.cuda.Event(), release=torch.cuda.Event(), released=False,
+                     copied=torch.cuda.Event(), staged=False)
             self._slots[i] = s
         if s["host"] is None or s["host"].numel() < total:
             if s["dev"] is not None:
@@ -211,6 +212,11 @@ class EpisodeLoader:
         mclass += [int(e["class_id"]) + 1 for e in eps]
         items, total = tf.plan(images, masks)
         sl = self._slot(i, total, max(im.shape[0] for im in images), nb)
+        if sl["staged"]:
+            # The H2D copy of this slot's PREVIOUS batch reads the same pinned bytes asynchronously; stream
+            # waits order GPU work only, and a consumer that never synchronises lets this thread run several
+            # batches ahead of the GPU.  Block here (CPU) until that copy has left the host buffer.
+            sl["copied"].synchronize()
         fill_staging(sl["host"], items)
         n_sup = nb * self.s
         img_out = [sl["sup"][j] for j in range(n_sup)] + [sl["qry"][j] for j in range(nb)]
@@ -220,6 +226,8 @@ class EpisodeLoader:
             if sl["released"]:          # the consumer's work on this buffer set's previous batch
                 self.stream.wait_event(sl["release"])
             sl["dev"][:total].copy_(sl["host"][:total], non_blocking=True)
+            sl["copied"].record(self.stream)
+            sl["staged"] = True
             tf.launch(items, sl["dev"].data_ptr(), img_out, sl["tmp"], pm1, bins, mclass, self.stream.cuda_stream)
             sl["event"].record(self.stream)
         cid = torch.tensor([int(e["class_id"]) for e in eps], dtype=torch.long)

@@ -16,12 +16,40 @@ import torch
 NCLASS = {"pascal": 20, "coco": 80, "fss": 1000, "paco_part": 448, "pascal_part": 100, "lvis": 1203}
 
 
-def fold_class_ids(benchmark, fold, nfolds=4, split="val"):
-    """evaluation_util/data/coco.py:64-70 (same rule for pascal): classes of a fold."""
+def fold_class_ids(benchmark, fold, nfolds=None, split="val", cat_ids=None):
+    """Classes a dataset split evaluates / trains on (`dataset.class_ids`, logger.py:15), per benchmark:
+      coco   (evaluation_util/data/coco.py:64-70)    interleaved: val = fold + nfolds*v, v < nclass/nfolds
+      pascal (evaluation_util/data/pascal.py:115-123) contiguous:  val = fold*n + i,     i < nclass/nfolds
+      fss    (evaluation_util/data/fss.py:100-107)    fixed ranges per split, no folds: trn 0..519,
+             val 520..759, test 760..999
+      lvis   (evaluation_util/data/lvis.py:66-90)     10 folds, interleaved over the annotation file's
+             category list -- pass that list as `cat_ids` (it comes from lvis_val.pkl / lvis_train.pkl,
+             not from arithmetic); the meter is then indexed by position (lvis.py:28-29).
+    Other benchmarks (paco_part, pascal_part) keep their class lists in dataset pickles: not derivable."""
     nclass = NCLASS[benchmark]
-    n = nclass // nfolds
-    val = [fold + nfolds * v for v in range(n)]
-    return val if split != "trn" else [c for c in range(nclass) if c not in val]
+    if benchmark == "coco":
+        nf = nfolds or 4
+        val = [fold + nf * v for v in range(nclass // nf)]
+        return val if split != "trn" else [c for c in range(nclass) if c not in val]
+    if benchmark == "pascal":
+        nf = nfolds or 4
+        n = nclass // nf
+        val = [fold * n + i for i in range(n)]
+        return val if split != "trn" else [c for c in range(nclass) if c not in val]
+    if benchmark == "fss":
+        return {"trn": list(range(0, 520)), "val": list(range(520, 760)), "test": list(range(760, 1000))}[split]
+    if benchmark == "lvis":
+        if cat_ids is None:
+            raise ValueError("lvis class ids come from the annotation pickles (lvis.py:66-90): pass cat_ids")
+        nf = nfolds or 10
+        cats = list(cat_ids)
+        if split == "trn":
+            raise NotImplementedError("lvis training split: class list = train categories minus the fold's "
+                                      "validation categories (lvis.py:84), both from the annotation pickles")
+        picked = [cats[fold + nf * v] for v in range(len(cats) // nf)]
+        return sorted(range(len(picked)))
+    raise NotImplementedError(f"class ids of benchmark {benchmark!r} live in its dataset files "
+                              "(evaluation_util/data/%s.py); pass them to AverageMeter directly" % benchmark)
 
 
 def classify_prediction(pred_mask, gt_mask, query_ignore_idx=None, ignore_index=255):
@@ -58,7 +86,14 @@ class AverageMeter:
         self.union_buf.index_add_(1, cid, union_b.to(self.union_buf.device, torch.int64))
 
     def update_from_counts(self, counts, class_id):
-        """counts [B, 4] int64 = inter0, inter1, union0, union1 from dfw_seg_postprocess."""
+        """counts [B, 4] int64 = inter0, inter1, union0, union1 from dfw_seg_postprocess.  On the GPU this
+        is one library kernel (dfw_meter_update: int64 atomics, exact in any order); CPU buffers (the gloo
+        rehearsal, host-side checks) take the index_add_ form of logger.py:35-37."""
+        if self.intersection_buf.is_cuda:
+            from . import ops
+            cid = class_id.to(self.intersection_buf.device, torch.int64).contiguous()
+            ops.meter_update(counts.contiguous(), cid, self.intersection_buf, self.union_buf)
+            return
         self.update(counts[:, 0:2].t(), counts[:, 2:4].t(), class_id)
 
     def all_reduce(self, group=None):

@@ -126,7 +126,7 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
-            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, fuse_gn_in=None):
+            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, fuse_gn_in=None, act=L.ACT_NONE):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
@@ -166,7 +166,7 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     a.taps, a.Cin, a.Hi, a.Wi, a.Ho, a.Wo = 9, Cin, Hi, Wi, Ho, Wo
     a.stride, a.pad, a.ups = stride, pad, int(ups)
     a.rows_per_img = Ho * Wo
-    a.out_scale = out_scale
+    a.out_scale, a.act = out_scale, act
     a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else L.OUT_T
     a.splitk = 0 if splitk is None else splitk
     a.batch, a.dtype = 1, _dt(x)
@@ -299,17 +299,38 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, out_scale=1.0, gn_groups=0):
+def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, out_scale=1.0, gn_groups=0,
+               out=None, gn_part=None):
     """Boundary conv with Cin <= 8: x NCHW fp32 [B, Cin, H, W], w fp32 [Cout, taps, Cin].
-    gn_groups: also emit the GroupNorm partial sums of the output where the kernel supports it (y._gn_stats)."""
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
-    B, Cin, H, W = x.shape
+    gn_groups: also emit the GroupNorm partial sums of the output where the kernel supports it (y._gn_stats).
+    x may be a list/tuple of up to three such tensors (same Cin, H, W): the batch is their concatenation,
+    read in place (no torch.cat).
+    out: write into this tensor instead of allocating -- NHWC: a batch slice of a larger contiguous buffer;
+    NCHW fp32: a view [B, cout, H, W] whose channel planes are contiguous (a channel slice of a wider NCHW
+    tensor is fine: the batch stride travels as y_bstride).  gn_part: the matching [B, chunks, groups, 2]
+    slice of a larger partial-sum buffer (several conv_small calls filling one batch)."""
+    xs = list(x) if isinstance(x, (list, tuple)) else [x]
+    assert 1 <= len(xs) <= 3
+    for t in xs:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4 and t.shape[1:] == xs[0].shape[1:]
+    x = xs[0]
+    _, Cin, H, W = x.shape
+    B = sum(t.shape[0] for t in xs)
     assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == cout * taps * Cin
-    if nchw_f32_out:
-        y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
-    else:
-        y = torch.empty(B, H, W, cout, dtype=dtype, device=x.device)
     a = L.ConvSmallArgs()
+    if len(xs) > 1:
+        a.x1, a.b0 = xs[1].data_ptr(), xs[0].shape[0]
+        a.b1 = a.b0 + xs[1].shape[0]
+        if len(xs) > 2:
+            a.x2 = xs[2].data_ptr()
+    if nchw_f32_out:
+        y = out if out is not None else torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+        assert y.shape == (B, cout, H, W) and y.dtype == torch.float32
+        assert y.stride(3) == 1 and y.stride(2) == W and y.stride(1) == H * W
+        a.y_bstride = y.stride(0) if B > 1 else cout * H * W
+    else:
+        y = out if out is not None else torch.empty(B, H, W, cout, dtype=dtype, device=x.device)
+        assert y.shape == (B, H, W, cout) and y.dtype == dtype and y.is_contiguous()
     a.x, a.W, a.bias, a.y = x.data_ptr(), w.data_ptr(), _p(_f32(bias, "bias")), y.data_ptr()
     a.B, a.Cin, a.H, a.Wd, a.Cout, a.taps, a.ldy = B, Cin, H, W, cout, taps, cout
     a.in_scale, a.out_scale = in_scale, out_scale
@@ -320,13 +341,33 @@ def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, 
         a.gn_groups = gn_groups
         chunks = L.lib().dfw_conv_small_gn_chunks(C.byref(a))
         if chunks > 0:
-            part = torch.empty(B, chunks, gn_groups, 2, dtype=torch.float32, device=x.device)
+            part = gn_part if gn_part is not None else torch.empty(B, chunks, gn_groups, 2, dtype=torch.float32, device=x.device)
+            assert part.shape == (B, chunks, gn_groups, 2) and part.is_contiguous() and part.dtype == torch.float32
             a.gn_partial = part.data_ptr()
             stats = (part, chunks, gn_groups)
     L.check(L.lib().dfw_conv_small(C.byref(a), _stream()), "dfw_conv_small")
     if stats is not None:
         y._gn_stats = stats
     return y
+
+
+def conv_small_gn_chunks(x_shape, cout, taps, dtype, gn_groups):
+    """Chunks per image of conv_small's fused GroupNorm partial sums for this shape (0: unsupported)."""
+    B, Cin, H, W = x_shape
+    a = L.ConvSmallArgs()
+    a.B, a.Cin, a.H, a.Wd, a.Cout, a.taps, a.ldy = B, Cin, H, W, cout, taps, cout
+    a.out_mode, a.dtype, a.gn_groups = L.OUT_T, _DT[dtype], gn_groups
+    a.x = 16    # alignment of the input pointer is part of the kernel choice: torch allocations are 16-byte aligned
+    return L.lib().dfw_conv_small_gn_chunks(C.byref(a))
+
+
+def meter_update(counts, class_id, inter_buf, union_buf):
+    """AverageMeter.update on device: int64 atomics into the two [2, nclass] buffers (logger.py:35-37)."""
+    assert counts.dtype == torch.int64 and counts.is_contiguous() and counts.shape[1] == 4
+    assert class_id.dtype == torch.int64 and class_id.is_contiguous() and class_id.shape[0] == counts.shape[0]
+    assert inter_buf.dtype == torch.int64 and inter_buf.is_contiguous() and union_buf.is_contiguous()
+    L.check(L.lib().dfw_meter_update(counts.data_ptr(), class_id.data_ptr(), inter_buf.data_ptr(), union_buf.data_ptr(),
+                                     counts.shape[0], inter_buf.shape[1], _stream()), "dfw_meter_update")
 
 
 def softmax_rows(x, dtype, scale=1.0):
@@ -375,16 +416,21 @@ def timestep_embedding(timesteps, dim, dtype, flip_sin_to_cos=True, freq_shift=0
     return out
 
 
-def seg_postprocess(x, gt=None, r_threshold=0.25):
-    """x: decoder output [B, 3, H, W] fp32 -> (uint8 [B,3,H,W], counts int64 [B,4] or None)."""
+def seg_postprocess(x, gt=None, r_threshold=0.25, threshold=0.0, batch_max=False, u8_out=None, counts_out=None,
+                    scratch=None):
+    """x: decoder output [B, 3, H, W] fp32 -> (uint8 [B,3,H,W], counts int64 [B,4] or None).
+    r_threshold > 0: dynamic threshold r_threshold * max (per image, or over the batch tensor when
+    batch_max -- main_oss.py:131 read literally); else the fixed `threshold` (main_oss.py:134-135)."""
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[1] == 3
     B, _, H, W = x.shape
-    u8 = torch.empty(B, 3, H, W, dtype=torch.uint8, device=x.device)
-    scratch = torch.empty(B, dtype=torch.int32, device=x.device)
+    u8 = u8_out if u8_out is not None else torch.empty(B, 3, H, W, dtype=torch.uint8, device=x.device)
+    if scratch is None:
+        scratch = torch.empty(B, dtype=torch.int32, device=x.device)
     counts = None
     if gt is not None:
         assert gt.dtype == torch.uint8 and gt.is_contiguous() and gt.shape == (B, H, W)
-        counts = torch.empty(B, 4, dtype=torch.int64, device=x.device)
-    L.check(L.lib().dfw_seg_postprocess(x.data_ptr(), u8.data_ptr(), _p(gt), _p(counts), scratch.data_ptr(),
-                                        B, H, W, float(r_threshold), _stream()), "dfw_seg_postprocess")
+        counts = counts_out if counts_out is not None else torch.empty(B, 4, dtype=torch.int64, device=x.device)
+    L.check(L.lib().dfw_seg_postprocess_ex(x.data_ptr(), u8.data_ptr(), _p(gt), _p(counts), scratch.data_ptr(),
+                                           B, H, W, float(r_threshold), float(threshold), int(bool(batch_max)),
+                                           _stream()), "dfw_seg_postprocess")
     return u8, counts

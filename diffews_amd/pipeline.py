@@ -12,7 +12,8 @@ Differences that are deliberate:
   * `rgb_paths` is ignored (the reference opens each path and throws the result away, P:312-316);
   * inner batching uses the explicit `batch_size`, not the VRAM lookup table (P:397-407);
   * `run_episodes()` is the fused fast path the launcher/bench use: z0 = -v is folded into the
-    UNet's conv_out epilogue and the threshold + intersection/union counts stay on device.
+    UNet's conv_out epilogue and the threshold + intersection/union counts stay on device; with
+    `use_graph` / `captured=True` the whole step is one HIP-graph replay owned by the pipeline.
 Only the segmentation task is implemented; the reference treats every mode except 'depth' as
 'seg' (`mode == 'seg' or 'semseg'` is always truthy, P:280).
 """
@@ -39,6 +40,27 @@ def chw2hwc(chw):
     return np.moveaxis(chw, 0, -1) if isinstance(chw, np.ndarray) else chw.permute(1, 2, 0)
 
 
+def load_empty_text_embed(checkpoint, tokenizer=None):
+    """CLIP("") of a diffusers checkpoint directory -> [1, L, cross_attention_dim] fp32 (P:585-601):
+    `tokenizer("", padding="do_not_pad", max_length=model_max_length, truncation=True)` => [BOS, EOS], then
+    `text_encoder(ids)[0]`.  Uses `transformers` on the host (the CLIP tower is a constant input of the
+    hot path); `tokenizer` may be the launcher's own CLIPTokenizer (E:351-353)."""
+    import os
+    from transformers import CLIPTextModel, CLIPTokenizer
+    if checkpoint is None:
+        raise ValueError("need text_embeds, a text_encoder, or a checkpoint directory holding text_encoder/ and tokenizer/")
+    enc_dir = os.path.join(checkpoint, "text_encoder")
+    if not os.path.isdir(enc_dir):
+        raise FileNotFoundError(f"{enc_dir} not found: pass text_embeds=[1, L, D] or text_encoder=")
+    if tokenizer is None:
+        tokenizer = CLIPTokenizer.from_pretrained(os.path.join(checkpoint, "tokenizer"))
+    enc = CLIPTextModel.from_pretrained(enc_dir).float().eval()
+    ids = tokenizer("", padding="do_not_pad", max_length=tokenizer.model_max_length, truncation=True,
+                    return_tensors="pt").input_ids
+    with torch.no_grad():
+        return enc(ids)[0].float()
+
+
 class MarigoldPipelineRGBLatentNoise:
     rgb_latent_scale_factor = 0.18215   # P:120-124
     seg_latent_scale_factor = 0.18215
@@ -55,6 +77,7 @@ class MarigoldPipelineRGBLatentNoise:
         self.empty_text_embed = text_embeds
         self.test_timestep = 1
         self.fold_conditioning = True   # run_episodes: precompute the constant conditioning once
+        self.use_graph = False          # run_episodes: replay the step as one HIP graph (see run_episodes)
         self.device = unet.device
         self.dtype = unet.dtype
         self._graphs = {}
@@ -67,6 +90,11 @@ class MarigoldPipelineRGBLatentNoise:
         from .unet import MyUNet2DConditionModel
         from .vae import AutoencoderKL
         dt = torch_dtype or torch.bfloat16
+        if text_embeds is None and text_encoder is None:
+            # evaluation_util/main_oss.py:355-369 passes text_embeds=None and no text_encoder: diffusers then
+            # loads CLIPTextModel from <checkpoint>/text_encoder and P:585-601 runs it on "" in every call.
+            # The prompt is a per-checkpoint constant: evaluate it ONCE here (host, fp32) and keep the result.
+            text_embeds = load_empty_text_embed(checkpoint, tokenizer)
         if unet is None:
             unet = MyUNet2DConditionModel.from_pretrained(checkpoint, subfolder="unet", torch_dtype=dt)
         if vae is None:
@@ -100,13 +128,12 @@ class MarigoldPipelineRGBLatentNoise:
         """P:839-862: mean of quant_conv(encoder(x)) times the latent scale (no sampling)."""
         h = self.vae.encoder(rgb_in.to(self.device))
         lc = self.vae.config["latent_channels"]
-        moments = self.vae.quant_conv(h, out_scale=self.rgb_latent_scale_factor)
-        return moments[:, :lc].contiguous()
+        return self.vae.quant_conv(h, out_scale=self.rgb_latent_scale_factor, channels=lc)
 
     def decode_seg(self, seg_latent):
-        """P:887-905."""
+        """P:887-905; the clip to [-1, 1] (P:903) happens in the decoder's last conv epilogue."""
         z = self.vae.post_quant_conv(seg_latent.to(self.device), in_scale=1.0 / self.seg_latent_scale_factor)
-        return self.vae.decoder(z).clip(-1, 1)
+        return self.vae.decoder(z, clamp=True)
 
     @torch.no_grad()
     def single_infer(self, rgb_in_ref, rgb_in_tag, gt_in_ref, clip_rgb_in=None, num_inference_steps=1,
@@ -152,7 +179,8 @@ class MarigoldPipelineRGBLatentNoise:
 
     # ------------------------------------------------------------------ fused fast path
     @torch.no_grad()
-    def run_episodes(self, support_imgs, query_img, support_masks, query_gt=None, r_threshold=0.25):
+    def run_episodes(self, support_imgs, query_img, support_masks, query_gt=None, r_threshold=0.25, threshold=0.0,
+                     batch_max=False, captured=None):
         """One denoising step for a batch of episodes, everything on device.
 
         support_imgs / support_masks [b*s, 3, H, W], query_img [b, 3, H, W] in [-1, 1];
@@ -161,35 +189,104 @@ class MarigoldPipelineRGBLatentNoise:
         counts [b,4] int64 = inter0, inter1, union0, union1 or None).
         Equivalent to single_infer(num_inference_steps=1) when the scheduler is the reference's
         degenerate DDIM (z0 = -v); falls back to it otherwise.
+        r_threshold / threshold / batch_max: the launcher's thresholding flags (main_oss.py:128-135; see
+        ops.seg_postprocess).
+
+        captured (default: self.use_graph): replay the whole step (~750 kernel launches) as ONE HIP graph,
+        captured on first use per (b, s, H, W, flags) into static buffers.  The inputs are copied into the
+        graph's input buffers and the returned tensors are the graph's output buffers: they are
+        overwritten by the next captured call with the same key (consume or clone them first).
         """
         sched = self.scheduler
         sched.set_timesteps(1, device=self.device)
         t = sched.timesteps[0]
         if not sched.z0_is_neg_v(t):
             seg, lat = self.single_infer(support_imgs, query_img, support_masks, return_latents=True)
-            dec = seg / 255.0 * 2.0 - 1.0
-            z0 = lat["z0"]
+            dec = (seg / 255.0 * 2.0 - 1.0).contiguous()
+            seg_u8, counts = ops.seg_postprocess(dec, query_gt, r_threshold, threshold, batch_max)
+            return dict(z0=lat["z0"], dec=dec, seg_u8=seg_u8, counts=counts)
+        tt = t * self.test_timestep
+        folded = self._fold_conditioning(tt)      # host + load-time work: never inside a capture
+        dev = self.device
+        ins = dict(support_imgs=support_imgs.to(dev, torch.float32).contiguous(),
+                   query_img=query_img.to(dev, torch.float32).contiguous(),
+                   support_masks=support_masks.to(dev, torch.float32).contiguous(),
+                   query_gt=None if query_gt is None else query_gt.to(dev).contiguous())
+        flags = (float(r_threshold), float(threshold), bool(batch_max))
+
+        def step(support_imgs, query_img, support_masks, query_gt=None):
+            return self._episodes_step(support_imgs, query_img, support_masks, query_gt, tt, folded, flags)
+        if captured is None:
+            captured = self.use_graph
+        if not captured:
+            return step(**ins)
+        key = (tuple(ins["support_imgs"].shape), tuple(ins["query_img"].shape), query_gt is not None, flags,
+               float(tt), folded, getattr(self, "_fold_key", None))
+        return self._replay(key, step, ins)
+
+    def _episodes_step(self, support_imgs, query_img, support_masks, query_gt, tt, folded, flags):
+        """The kernels of one step; every buffer it touches is written by a library kernel (no torch.cat /
+        slice-assign / clip passes): conv_in reads the three image groups in place, quant_conv writes the
+        latent means straight into cat([rgb, mask]) (P:674) and z_tag, conv_out folds z0 = -v, the decoder's
+        last conv clips to [-1, 1] (P:903)."""
+        b, n_sup = query_img.shape[0], support_imgs.shape[0]
+        lc = self.vae.config["latent_channels"]
+        # one VAE-encoder launch train for all 2s+1 image groups (weights read once)
+        mom = self.vae.encoder([support_imgs, support_masks, query_img])       # [2 n_sup + b, 2 lc, h, w] fp32
+        h, w = mom.shape[-2:]
+        cond_ref = torch.empty(n_sup, 2 * lc, h, w, dtype=torch.float32, device=mom.device)
+        z_tag = torch.empty(b, lc, h, w, dtype=torch.float32, device=mom.device)
+        qc, sf = self.vae.quant_conv, self.rgb_latent_scale_factor
+        qc(mom[:n_sup], out_scale=sf, out=cond_ref[:, :lc], channels=lc)               # z_ref      (P:649)
+        qc(mom[n_sup:2 * n_sup], out_scale=sf, out=cond_ref[:, lc:], channels=lc)      # z_mask_ref (P:651)
+        qc(mom[2 * n_sup:], out_scale=sf, out=z_tag, channels=lc)                      # z_tag      (P:650)
+        # support + query passes in layer lock-step (one trunk pass over [support ; query], weights
+        # read once); z0 = -v folded into conv_out.  Same per-image arithmetic as P:715-725.
+        if folded:
+            z0 = self.unet.forward_pair(cond_ref, z_tag, tt, out_scale=-1.0)
         else:
-            b = query_img.shape[0]
-            n_sup = support_imgs.shape[0]
-            # one VAE-encoder launch train for all 2s+1 image groups (weights read once)
-            allimg = torch.cat([support_imgs, support_masks, query_img], dim=0).to(self.device)
-            z_all = self.encode_rgb(allimg)
-            z_ref, z_gt, z_tag = z_all[:n_sup], z_all[n_sup:2 * n_sup], z_all[2 * n_sup:]
-            cond_ref = torch.cat([z_ref, z_gt], dim=1)
-            tt = t * self.test_timestep
-            # support + query passes in layer lock-step (one trunk pass over [support ; query], weights
-            # read once); z0 = -v folded into conv_out.  Same per-image arithmetic as P:715-725.
-            if self._fold_conditioning(tt):
-                z0 = self.unet.forward_pair(cond_ref, z_tag.contiguous(), tt, out_scale=-1.0)
-            else:
-                embed = self.encode_clip_feature().to(self.device)
-                ehs = embed.repeat((b, 1, 1))
-                ehs_ref = ehs.repeat((n_sup // b, 1, 1))
-                z0 = self.unet.forward_pair(cond_ref, z_tag.contiguous(), tt, ehs_ref, ehs, out_scale=-1.0)
-            dec = self.decode_seg(z0)
-        seg_u8, counts = ops.seg_postprocess(dec.contiguous(), query_gt, r_threshold)
+            embed = self.encode_clip_feature().to(self.device)
+            ehs = embed.repeat((b, 1, 1))
+            ehs_ref = ehs.repeat((n_sup // b, 1, 1))
+            z0 = self.unet.forward_pair(cond_ref, z_tag, tt, ehs_ref, ehs, out_scale=-1.0)
+        dec = self.decode_seg(z0)
+        seg_u8, counts = ops.seg_postprocess(dec, query_gt, *flags)
         return dict(z0=z0, dec=dec, seg_u8=seg_u8, counts=counts)
+
+    def _replay(self, key, step, ins):
+        """HIP-graph cache of the fused step: capture once per key into static input buffers, then one
+        graph launch per call (the eager path pays ~750 ctypes launches of host time per step)."""
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = {k: (None if v is None else v.clone()) for k, v in ins.items()}
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):           # eager warm-up: allocator pools, per-batch folded rows
+                step(**static_in)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step(**static_in)
+            ent = (graph, static_in, out)
+            self._graphs[key] = ent
+        graph, static_in, out = ent
+        for k, v in ins.items():
+            if v is not None and v.data_ptr() != static_in[k].data_ptr():
+                static_in[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out
+
+    def episode_input_buffers(self, b, nshot, res, with_gt=True, r_threshold=0.25, threshold=0.0, batch_max=False):
+        """Static input tensors of the captured step for this shape (after its first captured call): a
+        producer (e.g. the input pipeline) may write episodes straight into them and pass them to
+        run_episodes(captured=True), which then skips the staging copy."""
+        for key, (_, static_in, _) in self._graphs.items():
+            if key[0] == (b * nshot, 3, res, res) and key[1] == (b, 3, res, res) and key[2] == with_gt \
+                    and key[3] == (float(r_threshold), float(threshold), bool(batch_max)):
+                return static_in
+        return None
 
     # ------------------------------------------------------------------ __call__ (P:223-583)
     @torch.no_grad()

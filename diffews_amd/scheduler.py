@@ -89,8 +89,11 @@ class DDIMSchedulerCustomized:
         return a_t, a_prev
 
     def z0_is_neg_v(self, timestep):
+        """True when step() reduces to pred_original_sample == -model_output: v-prediction at alpha_bar == 0
+        AND no clamp of x0 (with clip_sample the generic step() clamps to +-clip_sample_range; the reference's
+        scheduler_config.json sets clip_sample false)."""
         a_t, _ = self._coeffs(timestep)
-        return self.config["prediction_type"] == "v_prediction" and a_t == 0.0
+        return self.config["prediction_type"] == "v_prediction" and a_t == 0.0 and not self.config["clip_sample"]
 
     def step(self, model_output, timestep, sample, eta=0.0, return_dict=True):
         """DDIM step, eta = 0 (diffusers DDIMScheduler.step formulas (12)/(16))."""

@@ -32,6 +32,21 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
+def _resolve_device(d):
+    """torch.device with the index filled in ("cuda" -> "cuda:<current>"), so `.to("cuda:0")` on an engine that
+    lives on "cuda" is recognised as a no-op instead of repacking 866 M parameters (E:371 `pipe.to(device)`)."""
+    d = torch.device(d)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return d
+
+
+def _needs_rebuild(self, device, dtype):
+    if dtype is not None and dtype != self.dtype:
+        return True
+    return device is not None and _resolve_device(device) != _resolve_device(self.device)
+
+
 class _Resnet:
     def __init__(self, sd, p, dev, dt, eps, groups):
         g = lambda k: sd[p + k]
@@ -103,15 +118,19 @@ class _Transformer:
         if h * L_ctx > 64:
             self.fold2 = None
             return
-        k, v = kv[:, :C].float(), kv[:, C:2 * C].float()            # [L, C]
-        wq, wo = self.w_q2.float(), self.w_o2.float()               # [C_out, C_in]
-        G = torch.zeros(64, C, dtype=torch.float32, device=kv.device)
-        Ut = torch.zeros(C, 64, dtype=torch.float32, device=kv.device)
+        # load-time constant folding on the HOST in fp32 (like the weight repacking): a few hundred
+        # [L, 64] x [64, C] products per checkpoint, no device GEMM library involved
+        dev = kv.device
+        kv = kv.float().cpu()
+        k, v = kv[:, :C], kv[:, C:2 * C]                             # [L, C]
+        wq, wo = self.w_q2.float().cpu(), self.w_o2.float().cpu()    # [C_out, C_in]
+        G = torch.zeros(64, C, dtype=torch.float32)
+        Ut = torch.zeros(C, 64, dtype=torch.float32)
         for hh in range(h):
             blk = slice(hh * 64, (hh + 1) * 64)
             G[hh * L_ctx:(hh + 1) * L_ctx] = (64 ** -0.5) * (k[:, blk] @ wq[blk, :])       # [L, C]
             Ut[:, hh * L_ctx:(hh + 1) * L_ctx] = wo[:, blk] @ v[:, blk].t()                # [C, L]
-        self.fold2 = (G.to(self.w_q2.dtype).contiguous(), Ut.to(self.w_q2.dtype).contiguous(), L_ctx)
+        self.fold2 = (G.to(dev, self.w_q2.dtype).contiguous(), Ut.to(dev, self.w_q2.dtype).contiguous(), L_ctx)
 
     def clear_bank(self):
         self.k_bank = None
@@ -290,7 +309,9 @@ class MyUNet2DConditionModel:
             t.clear_bank()
 
     def to(self, device=None, dtype=None):
-        if dtype is not None and dtype != self.dtype or device is not None and torch.device(device) != self.device:
+        if isinstance(device, torch.dtype):      # nn.Module.to(dtype) call form
+            device, dtype = None, device
+        if _needs_rebuild(self, device, dtype):
             self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
                           device=device or self.device)
         return self
@@ -325,8 +346,6 @@ class MyUNet2DConditionModel:
         in_dtype = sample.dtype
         x_in = sample.to(device=dev, dtype=torch.float32).contiguous()
         B, Cin, h, w = x_in.shape
-        if (h % 8 or w % 8) and False:
-            raise ValueError("latent size must be divisible by 8")
         # ---- 1. time (U:991-1015)
         c0 = cfg["block_out_channels"][0]
         kv_all = None
@@ -434,8 +453,8 @@ class MyUNet2DConditionModel:
             L_ctx = ehs.shape[1]
             ehs2d = ehs.reshape((n_ref + bq) * L_ctx, ehs.shape[2]).contiguous()
         x = torch.empty(n_ref + bq, zq.shape[2], zq.shape[3], c0, dtype=dt, device=dev)
-        x[:n_ref] = ops.conv_small(zr, self.w_in_ref, self.b_in_ref, c0, 9, dt)
-        x[n_ref:] = ops.conv_small(zq, self.w_in, self.b_in, c0, 9, dt)
+        ops.conv_small(zr, self.w_in_ref, self.b_in_ref, c0, 9, dt, out=x[:n_ref])   # conv_in_ref (U:1119)
+        ops.conv_small(zq, self.w_in, self.b_in, c0, 9, dt, out=x[n_ref:])           # conv_in     (U:1121)
         out = self._trunk(x, tproj, ehs2d, L_ctx, n_ref, out_scale, kv_all)
         return out[n_ref:]
 

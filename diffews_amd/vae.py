@@ -9,7 +9,7 @@ import torch
 
 from . import _lib as L
 from . import ops, packing, weights
-from .unet import _Cfg, _Conv
+from .unet import _Cfg, _Conv, _needs_rebuild
 
 
 class _VaeResnet:
@@ -96,7 +96,12 @@ class _Encoder:
 
     @torch.no_grad()
     def __call__(self, x):
-        x = x.to(dtype=torch.float32).contiguous()
+        """x: [n, 3, H, W], or a list of up to three such tensors encoded as ONE batch (their concatenation,
+        read in place by conv_in -- the support images, support masks and query images of P:649-651)."""
+        if isinstance(x, (list, tuple)):
+            x = [t.to(dtype=torch.float32).contiguous() for t in x]
+        else:
+            x = x.to(dtype=torch.float32).contiguous()
         h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups)
         for res, down in self.blocks:
             for r in res:
@@ -129,7 +134,8 @@ class _Decoder:
         self.conv_out = _Conv(sd, "decoder.conv_out.", dev, dt)
 
     @torch.no_grad()
-    def __call__(self, z):
+    def __call__(self, z, clamp=False):
+        """clamp: clip the image to [-1, 1] in the last conv's epilogue (decode_seg, P:903)."""
         z = z.to(dtype=torch.float32).contiguous()
         h = ops.conv_small(z, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups)
         h = self.mid(h)
@@ -140,7 +146,8 @@ class _Decoder:
                 h = ops.conv3x3(h, up.w, up.cout, bias=up.b, ups=True, gn_groups=self.groups)
         h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
         co = self.conv_out
-        return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True)  # [b, 3, H, W] fp32
+        return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True,
+                           act=L.ACT_CLAMP1 if clamp else L.ACT_NONE)  # [b, 3, H, W] fp32
 
 
 class _Conv1x1Boundary:
@@ -150,11 +157,19 @@ class _Conv1x1Boundary:
         self.w = packing.pack_conv_small(sd[p + "weight"]).to(dev)
         self.b = sd[p + "bias"].float().to(dev)
         self.cout, self.dt = sd[p + "weight"].shape[0], dt
+        self._head = {}
 
     @torch.no_grad()
-    def __call__(self, x, in_scale=1.0, out_scale=1.0):
-        return ops.conv_small(x.to(dtype=torch.float32).contiguous(), self.w, self.b, self.cout, 1, self.dt,
-                              nchw_f32_out=True, in_scale=in_scale, out_scale=out_scale)
+    def __call__(self, x, in_scale=1.0, out_scale=1.0, out=None, channels=None):
+        """channels: compute only the first `channels` outputs (the latent MEAN of quant_conv's moments,
+        P:858-861); out: NCHW fp32 view to write into (may be a channel slice of a wider tensor)."""
+        w, b, cout = self.w, self.b, self.cout
+        if channels is not None and channels != cout:
+            if channels not in self._head:
+                self._head[channels] = (w[:channels].contiguous(), b[:channels].contiguous())
+            (w, b), cout = self._head[channels], channels
+        return ops.conv_small(x.to(dtype=torch.float32).contiguous(), w, b, cout, 1, self.dt,
+                              nchw_f32_out=True, in_scale=in_scale, out_scale=out_scale, out=out)
 
 
 class _DiagonalGaussian:
@@ -207,7 +222,9 @@ class AutoencoderKL:
         weights.save_pretrained(path, dict(self.config), self._sd_cpu, subfolder)
 
     def to(self, device=None, dtype=None):
-        if dtype is not None and dtype != self.dtype or device is not None and torch.device(device) != self.device:
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        if _needs_rebuild(self, device, dtype):
             self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
                           device=device or self.device)
         return self

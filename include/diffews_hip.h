@@ -30,7 +30,7 @@ typedef void* dfw_stream_t; /* hipStream_t */
 
 enum { DFW_BF16 = 0, DFW_F16 = 1 };                       /* storage dtype of activations/weights */
 enum { DFW_OUT_T = 0, DFW_OUT_F32 = 1, DFW_OUT_NCHW_F32 = 2 };
-enum { DFW_ACT_NONE = 0, DFW_ACT_SILU = 1 };
+enum { DFW_ACT_NONE = 0, DFW_ACT_SILU = 1, DFW_ACT_CLAMP1 = 2 /* clamp to [-1, 1]: decode_seg, P:903 */ };
 enum {
   DFW_EINVAL = -1,   /* null pointer / non-positive size */
   DFW_ESHAPE = -2,   /* shape not supported by the kernel (alignment / multiple-of constraints) */
@@ -191,6 +191,15 @@ typedef struct {
    * dfw_groupnorm_args.pre_partial): gn_partial[B][chunks][gn_groups][2], chunks from
    * dfw_conv_small_gn_chunks() (0: not supported for this shape -- leave gn_partial NULL). */
   float* gn_partial; int32_t gn_groups;
+  /* DFW_OUT_NCHW_F32 only: element stride between the images of y (0 => Cout*H*Wd).  Lets the conv write
+   * its Cout channels into a channel slice of a wider NCHW tensor, e.g. the latent mean of the support
+   * image and of its mask straight into the two halves of `cat([rgb_latent, mask_latent], dim=1)` (P:674). */
+  int64_t y_bstride;
+  /* Optional: the input batch spread over up to three buffers (each NCHW fp32, contiguous, 16-byte aligned):
+   * images [0, b0) from x, [b0, b1) from x1, [b1, B) from x2.  x1 == NULL: all B images from x.  One launch
+   * then covers the support images, the support masks and the query images of an episode batch
+   * (P:649-651 encodes them in three calls) without first concatenating them. */
+  const float* x1; const float* x2; int32_t b0, b1;
 } dfw_conv_small_args;
 
 int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream);
@@ -232,6 +241,21 @@ int dfw_timestep_embedding(const float* timesteps, void* out, int32_t B, int32_t
 int dfw_seg_postprocess(const float* x, uint8_t* seg_u8, const uint8_t* gt, int64_t* counts,
                         uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
                         dfw_stream_t stream);
+/* Same with the launcher's other two choices (evaluation_util/main_oss.py:128-135):
+ *   r_threshold > 0: dynamic threshold r_threshold * max; batch_max == 0 takes the max per image (what the
+ *     reference computes at --bsz 1, the only batch size its E:128 `to_tensor` accepts; results do not
+ *     depend on how episodes are batched), batch_max != 0 takes it over the whole [B,3,H,W] tensor, as
+ *     `pred_mask.max()` literally reads for B > 1;
+ *   r_threshold <= 0: fixed `--threshold`: pred = mean_c(u8/255) > threshold (> 0 required with gt). */
+int dfw_seg_postprocess_ex(const float* x, uint8_t* seg_u8, const uint8_t* gt, int64_t* counts,
+                           uint32_t* scratch, int32_t B, int32_t H, int32_t Wd, float r_threshold,
+                           float threshold, int32_t batch_max, dfw_stream_t stream);
+
+/* AverageMeter.update on device (evaluation_util/common/logger.py:35-37): for every episode b,
+ * inter_buf[k][class_id[b]] += counts[b][k], union_buf[k][class_id[b]] += counts[b][2+k], k = 0, 1.
+ * Buffers are int64 [2][nclass] (exact, order-independent sums); class ids outside [0, nclass) are skipped. */
+int dfw_meter_update(const int64_t* counts, const int64_t* class_id, int64_t* inter_buf, int64_t* union_buf,
+                     int32_t B, int32_t nclass, dfw_stream_t stream);
 
 /*
  * Episode input transform (evaluation_util/data/dataset.py:36-40: Resize((S,S)) on the PIL image,

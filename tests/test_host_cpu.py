@@ -205,3 +205,72 @@ def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
     miou, fb, _ = meter.compute_iou()
     assert res["inter"] == meter.intersection_buf.tolist() and res["union"] == meter.union_buf.tolist()
     assert res["miou"] == float(miou) and res["fb"] == float(fb)
+
+
+def test_fold_class_ids_per_benchmark_match_reference_datasets():
+    """`dataset.class_ids` of DatasetCOCO / DatasetPASCAL / DatasetFSS (coco.py:64-70, pascal.py:115-123,
+    fss.py:100-107), captured by tests/golden/make_classid_goldens.py from the reference's own classes."""
+    import json
+    from diffews_amd import metrics
+    with open(os.path.join(os.path.dirname(__file__), "golden", "classid_goldens.json")) as f:
+        cases = json.load(f)
+    assert {c["benchmark"] for c in cases} == {"coco", "pascal", "fss"}
+    for c in cases:
+        assert metrics.fold_class_ids(c["benchmark"], c["fold"], split=c["split"]) == c["ids"], c["benchmark"]
+    # pascal folds are contiguous blocks, coco folds interleaved: they must differ
+    assert metrics.fold_class_ids("pascal", 1) == [5, 6, 7, 8, 9] and metrics.fold_class_ids("coco", 1)[:3] == [1, 5, 9]
+    # lvis: positions in the fold's category list (lvis.py:28-29, 83); list comes from the annotation file
+    assert metrics.fold_class_ids("lvis", 2, cat_ids=list(range(100, 160))) == list(range(6))
+    with pytest.raises(ValueError):
+        metrics.fold_class_ids("lvis", 0)
+    with pytest.raises(NotImplementedError):
+        metrics.fold_class_ids("paco_part", 0)
+
+
+def test_checkpoint_directory_and_empty_prompt_loading(tmp_path):
+    """The launcher's checkpoint layout (main_oss.py:338-369): unet/ vae/ scheduler/ text_encoder/ tokenizer/.
+    Host side of `MarigoldPipeline.from_pretrained(checkpoint, text_embeds=None)`: weights and configs load
+    back unchanged, and CLIP("") is evaluated once from the directory exactly as P:585-601 does
+    (tokenise "" unpadded -> [BOS, EOS] -> text_encoder(ids)[0])."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    from ckpt_util import make_checkpoint_dir
+    from diffews_amd import weights
+    from diffews_amd.pipeline import load_empty_text_embed
+    from diffews_amd.scheduler import DDIMSchedulerCustomized
+    ck = make_checkpoint_dir(tmp_path / "ckpt")
+    for sub, cfg, sd in (("unet", ck["ucfg"], ck["usd"]), ("vae", ck["vcfg"], ck["vsd"])):
+        assert weights.load_config(ck["root"], sub) == cfg
+        got = weights.load_state_dict(ck["root"], sub)
+        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    s = DDIMSchedulerCustomized.from_pretrained(ck["root"], subfolder="scheduler")
+    s.set_timesteps(1)
+    assert s.timesteps.tolist() == [1] and s.z0_is_neg_v(1)
+    e = load_empty_text_embed(ck["root"])
+    assert e.shape == (1, 2, ck["ucfg"]["cross_attention_dim"]) and e.dtype == torch.float32
+    assert torch.allclose(e, ck["text_embed"], atol=1e-6)
+    # the launcher hands over its own tokenizer (E:351-353): same ids, same embedding
+    from transformers import CLIPTokenizer
+    tok = CLIPTokenizer.from_pretrained(os.path.join(ck["root"], "tokenizer"))
+    assert torch.equal(load_empty_text_embed(ck["root"], tok), e)
+    with pytest.raises(FileNotFoundError):
+        load_empty_text_embed(str(tmp_path))          # no text_encoder/ there
+    with pytest.raises(ValueError):
+        load_empty_text_embed(None)
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` (the driver's command line, no RANK in the environment) spawns its own
+    ranks; where the node shows fewer than N GPUs it must fail loudly -- never print an n_gpus=1 line."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node could actually run 2 ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DFW_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "n_gpus" not in r.stdout and "refusing" in r.stderr
+    # under torchrun with a world size that contradicts --gpus: also an error, not a silent re-interpretation
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout

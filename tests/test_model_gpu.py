@@ -271,3 +271,89 @@ def test_not_worse_than_reference_precision(models):
     e_engine, e_lowp = rel(r["z0"], ref["z0"]), rel(low["z0"], ref["z0"])
     print(f"engine-vs-fp32 {e_engine:.3e}   torch-{dt}-vs-fp32 {e_lowp:.3e}")
     assert e_engine <= 1.25 * e_lowp
+
+
+def test_launcher_literal_from_pretrained(hip_lib, tmp_path):
+    """evaluation_util/main_oss.py:338-379 verbatim against a checkpoint DIRECTORY: unet / vae / tokenizer /
+    scheduler loaded from it, `MarigoldPipeline.from_pretrained(checkpoint, ..., text_embeds=None)` with no
+    text_encoder (the pipeline loads text_encoder/ itself and evaluates "" once, P:585-601), `.to(device)`,
+    `test_timestep`, `enable_xformers_memory_efficient_attention()`, then `pipe([...], mode='seg')` --
+    compared with the oracle run on the same checkpoint content."""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(__file__))
+    from ckpt_util import make_checkpoint_dir
+    from transformers import CLIPTokenizer
+    from diffews_amd.pipeline import MarigoldPipeline
+    from diffews_amd.scheduler import DDIMScheduler
+    from diffews_amd.unet import CustomUNet2DConditionModel
+    from diffews_amd.vae import AutoencoderKL
+    from oracle import pipeline as op
+    from oracle.unet import OracleUNet
+    from oracle.vae import OracleVAE
+    dt = torch.float16
+    ck = make_checkpoint_dir(tmp_path / "ckpt", dtype=dt)
+    checkpoint = ck["root"]
+    unet = CustomUNet2DConditionModel.from_pretrained(checkpoint, subfolder="unet", revision=None, torch_dtype=dt)  # E:338-345
+    vae = AutoencoderKL.from_pretrained(checkpoint, subfolder="vae", torch_dtype=dt)                              # E:347
+    tokenizer = CLIPTokenizer.from_pretrained(os.path.join(checkpoint, "tokenizer"))                             # E:351-353
+    scheduler = DDIMScheduler.from_pretrained(checkpoint, subfolder="scheduler")                                # E:366-367
+    pipe = MarigoldPipeline.from_pretrained(checkpoint, torch_dtype=dt, unet=unet, vae=vae, scheduler=scheduler,
+                                            tokenizer=tokenizer, controlnet=None, text_embeds=None,
+                                            image_projector=None, customized_head=None, image_encoder=None)  # E:355-369
+    packed = unet.w_in.data_ptr()
+    pipe = pipe.to(torch.device("cuda:0"))          # E:371 -- must not repack an engine that already lives there
+    assert unet.w_in.data_ptr() == packed and pipe.unet is unet
+    pipe.test_timestep = 1                          # E:373
+    pipe.enable_xformers_memory_efficient_attention()   # E:376
+    assert torch.allclose(pipe.encode_clip_feature().cpu(), ck["text_embed"], atol=1e-6)
+    sup, qry, msk = _episode(1, 1, 64, seed=9)
+    out = pipe([sup.cuda(), qry.cuda(), msk.cuda()], denoising_steps=1, ensemble_size=1, processing_res=64,
+               batch_size=1, show_progress_bar=False, mode="seg", rgb_paths=["unused.jpg"], seed=0)   # E:113-123
+    img = np.asarray(out.seg_colored)
+    assert img.shape == (64, 64, 3) and img.dtype == np.uint8 and out.uncertainty is None
+    ou = OracleUNet(**_kw(ck["ucfg"])); ou.load_state_dict(ck["usd"]); ou.eval()
+    ov = OracleVAE(**_kw(ck["vcfg"])); ov.load_state_dict(ck["vsd"]); ov.eval()
+    ref = op.single_infer(ou, ov, sup, qry, msk, ck["text_embed"])
+    ref_u8 = ref["seg"].clip(0, 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)
+    diff = np.abs(img.astype(np.int32) - ref_u8.astype(np.int32))
+    assert diff.mean() < 1.0 and np.percentile(diff, 99) <= 3, (diff.mean(), diff.max())
+    # a pipeline with neither embedding nor encoder nor checkpoint has nothing to evaluate "" with
+    with pytest.raises(ValueError):
+        MarigoldPipeline.from_pretrained(None, unet=unet, vae=vae, scheduler=scheduler)
+
+
+def test_captured_step_equals_eager(models):
+    """run_episodes(captured=True): the pipeline-owned HIP graph replays the same kernels -> identical bits,
+    for repeated calls with new inputs (static input buffers are refilled), with and without ground truth."""
+    pipe = models["pipe"]
+    gt = (torch.rand(2, 64, 64) > 0.5).to(torch.uint8).cuda()
+    for seed in (1, 2, 3):
+        sup, qry, msk = (t.cuda() for t in _episode(2, 1, 64, seed=seed))
+        e = pipe.run_episodes(sup, qry, msk, gt, captured=False)
+        e = {k: v.clone() for k, v in e.items()}
+        c = pipe.run_episodes(sup, qry, msk, gt, captured=True)
+        for k in ("z0", "dec", "seg_u8", "counts"):
+            assert torch.equal(e[k], c[k]), (seed, k)
+    assert len(pipe._graphs) == 1          # one capture, three replays
+    sup, qry, msk = (t.cuda() for t in _episode(1, 2, 64, seed=4))
+    e = pipe.run_episodes(sup, qry, msk, captured=False)["z0"].clone()
+    assert torch.equal(e, pipe.run_episodes(sup, qry, msk, captured=True)["z0"]) and len(pipe._graphs) == 2
+    bufs = pipe.episode_input_buffers(2, 1, 64)
+    assert bufs is not None and bufs["query_img"].shape == (2, 3, 64, 64)
+
+
+def test_encoder_multi_source_batch_equals_concat(models):
+    """The VAE encoder over [support imgs, support masks, query imgs] read in place (three buffers, one
+    conv_in launch) == the encoder over their torch.cat; quant_conv head writes == slices of the full conv."""
+    vae, pipe = models["vae"], models["pipe"]
+    sup, qry, msk = (t.cuda() for t in _episode(2, 2, 64, seed=6))
+    a = vae.encoder([sup, msk, qry])
+    b = vae.encoder(torch.cat([sup, msk, qry], 0))
+    assert torch.equal(a, b)
+    full = vae.quant_conv(a, out_scale=0.18215)
+    cond = torch.zeros(4, 8, 8, 8, device="cuda")
+    vae.quant_conv(a[:4], out_scale=0.18215, out=cond[:, :4], channels=4)
+    vae.quant_conv(a[4:8], out_scale=0.18215, out=cond[:, 4:], channels=4)
+    assert torch.equal(cond[:, :4], full[:4, :4]) and torch.equal(cond[:, 4:], full[4:8, :4])
+    assert torch.equal(pipe.encode_rgb(qry), full[8:, :4])

@@ -452,3 +452,36 @@ def test_seg_postprocess_bit_exact(ops):
         inter = torch.histc(same, bins=2, min=0, max=1)
         union = torch.histc(pm, bins=2, min=0, max=1) + torch.histc(g_, bins=2, min=0, max=1) - inter
         assert counts[b].cpu().tolist() == [int(inter[0]), int(inter[1]), int(union[0]), int(union[1])]
+
+
+def test_seg_postprocess_threshold_modes(ops):
+    """The launcher's other threshold choices (main_oss.py:128-135) for B > 1: `pred_mask.max()` over the whole
+    batch tensor (batch_max=True) and the fixed --threshold (r_threshold <= 0), bit-exact against a host
+    restatement; with neither flag the reference's shape assert fails -- rejected here."""
+    import numpy as np
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 4, 24, 40
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    x[1] *= 0.3                                     # images with different maxima: per-image != batch-global
+    x[2] *= 0.6
+    gt = (torch.rand(B, H, W, generator=g) > 0.5).to(torch.uint8)
+    u8_ref = ((x.clip(-1, 1) * 0.5 + 0.5) * 255).clip(0, 255).numpy().astype(np.uint8)
+    pred_t = torch.from_numpy(u8_ref).float().div(255)            # to_tensor of the uint8 image(s)
+
+    def counts_of(pm):
+        out = []
+        for b in range(B):
+            p_, g_ = pm[b].float(), gt[b].float()
+            inter = torch.histc(p_[p_ == g_], bins=2, min=0, max=1)
+            union = torch.histc(p_, bins=2, min=0, max=1) + torch.histc(g_, bins=2, min=0, max=1) - inter
+            out.append([int(inter[0]), int(inter[1]), int(union[0]), int(union[1])])
+        return out
+    _, c_glob = ops.seg_postprocess(x.cuda(), gt.cuda(), 0.25, batch_max=True)
+    assert c_glob.cpu().tolist() == counts_of(pred_t.mean(dim=1) > pred_t.max() * 0.25)
+    _, c_img = ops.seg_postprocess(x.cuda(), gt.cuda(), 0.25)
+    per_img = torch.stack([pred_t[b].mean(dim=0) > pred_t[b].max() * 0.25 for b in range(B)])
+    assert c_img.cpu().tolist() == counts_of(per_img) and c_img.cpu().tolist() != c_glob.cpu().tolist()
+    _, c_fix = ops.seg_postprocess(x.cuda(), gt.cuda(), 0.0, threshold=0.4)
+    assert c_fix.cpu().tolist() == counts_of(pred_t.mean(dim=1) > 0.4)
+    with pytest.raises(RuntimeError):
+        ops.seg_postprocess(x.cuda(), gt.cuda(), 0.0, threshold=0.0)

@@ -166,3 +166,28 @@ def test_evaluation_loop_over_host_episodes(hip_lib, tmp_path):
     b = evaluate.test_diffusion(pipe, n, nshot=1, res=S, batch=2, make_batch=make_batch)
     assert a[0] == b[0] and a[1] == b[1]
     assert torch.equal(a[2].intersection_buf, b[2].intersection_buf) and torch.equal(a[2].union_buf, b[2].union_buf)
+
+
+def test_loader_recycles_slots_without_consumer_sync(hip_lib, tmp_path):
+    """More than 2*(depth+2) batches with a consumer that never synchronises and is slow on the GPU: the
+    producer thread runs ahead of the device, so a slot's pinned staging buffer is refilled while its previous
+    H2D copy could still be pending -- every batch must still equal the host-built tensors (the loader
+    blocks on the slot's copy event before overwriting the host bytes)."""
+    from diffews_amd.input_pipeline import EpisodeLoader
+    S, b, depth = 96, 1, 1
+    n = 4 * (depth + 2) + 2
+    eps = _jpeg_episodes(tmp_path, n, 1, seed=77)
+    slow = torch.randn(4096, 4096, device="cuda")
+    keep = []
+    for batch in EpisodeLoader(eps, S, b, 1, depth=depth):
+        for _ in range(6):                       # ~ms of queued GPU work per batch, no host sync
+            slow = (slow @ slow).clamp_(-1, 1)
+        keep.append({k: v.clone() for k, v in batch.items()})   # device-side copies, still asynchronous
+    torch.cuda.synchronize()
+    assert len(keep) == n
+    for i, g in enumerate(keep):
+        e = eps[i]
+        assert int(g["class_id"][0]) == e["class_id"]
+        assert torch.equal(g["query_img"][0].cpu(), host_image(np.asarray(e["query_img"]), S))
+        assert torch.equal(g["support_imgs"][0].cpu(), host_image(np.asarray(e["support_imgs"][0]), S))
+        assert torch.equal(g["query_mask"][0].float().cpu(), host_mask(e["query_mask"], e["class_id"], S))
