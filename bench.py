@@ -223,6 +223,7 @@ def main():
                               captured=use_graph if captured is None else captured)
         meter.update_from_counts(r["counts"], cls)
         out["z0"] = r["z0"]
+        out["r"] = r
 
     # warm-up: eager steps, then (graph mode) the capture + replays; afterwards the episode tensors ARE the
     # graph's static input buffers, so a step starts with its inputs resident in HBM and copies nothing
@@ -265,6 +266,11 @@ def main():
         f"z0 finite={finite} |z0|={float(z0.abs().mean()):.4f}")
     if not finite:
         raise SystemExit("non-finite latents: invalid run")
+    if os.environ.get("DFW_BENCH_DEBUG"):
+        rr = out["r"]
+        log("[debug] counts", rr["counts"].tolist(), "u8 max", rr["seg_u8"].flatten(1).max(1).values.tolist(),
+            "dec min/max", float(rr["dec"].min()), float(rr["dec"].max()), "cls", cls.tolist(),
+            "inter", meter.intersection_buf[:, [0, 4, 8, 12]].tolist(), "union", meter.union_buf[:, [0, 4, 8, 12]].tolist())
 
     eager_ms = None
     if rank == 0 and use_graph:                  # the same step launched kernel by kernel (host-bound): recorded, not `value`

@@ -505,6 +505,16 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const uint8_t* u8, const
   }
 }
 
+// Zeroes the per-image max words and the count cells.  A kernel of the library, not hipMemsetAsync: inside a
+// captured HIP graph (ROCm 7.2) a small memset node replayed next to ordinary launches on the same stream was
+// observed to deposit another launch's kernel arguments in its destination (the per-image max then read as a
+// pointer and every prediction fell below the threshold).
+__global__ void seg_zero_kernel(uint32_t* mx, int B, unsigned long long* counts) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < B) mx[e] = 0u;
+  if (counts && e < 4 * B) counts[e] = 0ull;
+}
+
 __global__ void meter_update_kernel(const long long* counts, const long long* cls, unsigned long long* ib,
                                     unsigned long long* ub, int B, int nclass) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -681,16 +691,15 @@ extern "C" int dfw_seg_postprocess_ex(const float* x, uint8_t* seg_u8, const uin
   if (gt && !(r_threshold > 0.f) && !(threshold > 0.f)) return DFW_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int HW = H * Wd, per_img = 3 * HW;
-  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * sizeof(uint32_t), st);
-  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(seg_zero_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, st, scratch, B,
+                     (unsigned long long*)(gt ? counts : nullptr));
+  DFW_CHECK_LAUNCH();
   int bx = (per_img / 4 + 255) / 256;
   if (bx > 128) bx = 128;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(seg_u8_kernel, dim3(bx, B), dim3(256), 0, st, x, seg_u8, scratch, per_img);
   DFW_CHECK_LAUNCH();
   if (gt) {
-    e = hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int64_t), st);
-    if (e != hipSuccess) return (int)e;
     int cx = (HW / 4 + 255) / 256;
     if (cx > 64) cx = 64;
     if (cx < 1) cx = 1;

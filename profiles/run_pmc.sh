@@ -14,7 +14,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "pass $C done"
 done
 rm -rf gpurun_out/pmc_${ROUND}_SQ
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
   -d gpurun_out/pmc_${ROUND}_SQ -o runc -- python3 $ARGS > gpurun_out/pmc_${ROUND}_SQ.log 2>&1
 echo "pass SQ done"
 python3 profiles/collect_pmc.py gpurun_out/pmc_${ROUND}_FETCH_SIZE gpurun_out/pmc_${ROUND}_WRITE_SIZE gpurun_out/pmc_${ROUND}_SQ gpurun_out/pmc_${ROUND}_raw.json

@@ -124,7 +124,7 @@ def test_tiny_episode_against_committed_golden(hip_lib, dt):
     kw = {k: v for k, v in config.get("scheduler").items() if not k.startswith("_")}
     pipe = MarigoldPipelineRGBLatentNoise(unet, vae, DDIMSchedulerCustomized(**kw),
                                           text_embeds=weights.synthetic_text_embed(ucfg).to(rt).float())
-    tol = 4e-3 if dt == torch.float16 else 3e-2
+    tol = 3.5e-3 if dt == torch.float16 else 2.9e-2   # tiny config: 1.25 x measured (2.8e-3 / 2.3e-2)
     for c in fx["cases"]:
         bt = make_episode_batch(c["b"], c["nshot"], c["res"], seed=c["seed"], device="cuda")
         r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"])
@@ -135,10 +135,16 @@ def test_tiny_episode_against_committed_golden(hip_lib, dt):
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 def test_fullsize_episode_against_oracle_on_device(hip_lib, dt):
-    """BASELINE configs[1] / configs[2] sizes (SD-2.1 UNet + SD VAE, 512x512) against the fp32 ORACLE itself:
-    the oracle is plain torch, so on the GPU box it can run on the device (MIOpen / rocBLAS fp32 -- used here
-    as the checker only) and finishes in seconds where the CPU needs minutes.  Same weights (rounded to the
-    storage dtype) and inputs on both sides; tolerances are those of the tiny-config episode tests."""
+    """The EXACT BASELINE.json shapes -- configs[1] (512x512, 1-shot, batch 4), configs[2] (512x512, 5-shot,
+    batch 2: 6-image in-context latent, 24 576 keys at the 64x64 level) and configs[0]'s resolution (256x256,
+    1-shot, batch 1) -- SD-2.1 UNet + SD VAE, against the fp32 ORACLE itself: the oracle is plain torch, so on
+    the GPU box it can run on the device (MIOpen / rocBLAS fp32 -- used here as the checker only) and finishes
+    in seconds where the CPU needs minutes.  Same weights (rounded to the storage dtype) and inputs on both
+    sides.  Tile / split-K / GroupNorm-chunk plans depend on the batch, hence the exact batch sizes.
+    Tolerance on the parity tensor z0 (P:769): 1.25 x the measured error, which the per-stage trace
+    (profiles/r02_stage_trace_*.txt) shows to be the floor of ANY 16-bit-storage pipeline:
+    every residual-level stage adds exactly one storage rounding (2.9e-4 fp16 / 2.4e-3 bf16) and nothing else;
+    measured 1.45e-3 fp16 / 1.18e-2 bf16."""
     from diffews_amd import config, weights
     from diffews_amd.episodes import make_episode_batch
     from diffews_amd.pipeline import MarigoldPipelineRGBLatentNoise
@@ -162,13 +168,14 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt):
         pipe = MarigoldPipelineRGBLatentNoise(
             MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt), AutoencoderKL(vcfg, vsd, torch_dtype=dt),
             DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
-        tol = 4e-3 if dt == torch.float16 else 3e-2
-        for b, nshot in ((2, 1), (1, 5)):
-            bt = make_episode_batch(b, nshot, 512, seed=40 + nshot, device="cuda")
+        tol = 1.8e-3 if dt == torch.float16 else 1.5e-2
+        for b, nshot, res in ((4, 1, 512), (2, 5, 512), (1, 1, 256)):
+            bt = make_episode_batch(b, nshot, res, seed=40 + nshot + b, device="cuda")
             with torch.no_grad():
                 ref = OP.single_infer(ou, ov, bt["support_imgs"], bt["query_img"], bt["support_masks"], te.cuda())
             r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"])
-            assert rel(r["z0"], ref["z0"]) < tol, (b, nshot, rel(r["z0"], ref["z0"]))
+            assert rel(r["z0"], ref["z0"]) < tol, (b, nshot, res, rel(r["z0"], ref["z0"]))
+            print(f"[parity] {str(dt):15s} b={b} {nshot}-shot {res}x{res}: z0 rel L2 {rel(r['z0'], ref['z0']):.3e}")
             # decoder output in [0, 255] (P:790-795): mean absolute difference in uint8 levels
             seg_ref = ref["seg"].clip(0, 255)
             seg = (r["dec"].clip(-1, 1) * 0.5 + 0.5) * 255
@@ -223,6 +230,6 @@ def test_fullsize_other_resolutions_against_oracle_on_device(hip_lib):
             with torch.no_grad():
                 ref = OP.single_infer(ou, ov, sup, qry, msk, te.cuda())
             r = pipe.run_episodes(sup, qry, msk)
-            assert rel(r["z0"], ref["z0"]) < 4e-3, (H, W, rel(r["z0"], ref["z0"]))
+            assert rel(r["z0"], ref["z0"]) < 2.0e-3, (H, W, rel(r["z0"], ref["z0"]))
     finally:
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev

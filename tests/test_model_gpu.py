@@ -7,7 +7,7 @@ Tolerances, relative L2 against the fp32 oracle:
   per op (tests/test_ops_gpu.py): 6e-4 fp16 / 4e-3 bf16 -- inside north_star's "1e-3 relative fp16
       tolerance", which can only hold per op: 16-bit MFMA operands are re-rounded at every layer;
   one UNet pass (~60 sequential ops):           2e-3 fp16 / 2e-2 bf16;
-  whole episode z0 (VAE enc -> 2 UNet passes):  4e-3 fp16 / 3e-2 bf16 (measured 2.4-2.8e-3 / 2.0-2.3e-2;
+  whole episode z0 (VAE enc -> 2 UNet passes):  3.5e-3 fp16 / 2.9e-2 bf16 (measured 2.4-2.8e-3 / 2.0-2.3e-2;
       the oracle graph itself run by torch in fp16 / bf16 sits at 2.5e-3 / 2.4e-2 from its fp32 run);
 and, dtype-independent, the engine must be no further from the fp32 oracle than the *reference's own
 arithmetic at that precision* would be: the oracle cast to the same dtype (torch CPU, every op
@@ -19,7 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL_Z0 = {torch.float16: 2e-3, torch.bfloat16: 2e-2}   # one UNet pass / VAE half
-TOL_EP = {torch.float16: 4e-3, torch.bfloat16: 3e-2}   # whole episode
+TOL_EP = {torch.float16: 3.5e-3, torch.bfloat16: 2.9e-2}   # whole episode: 1.25 x the largest measured value
 
 
 def rel(a, b):
@@ -356,4 +356,27 @@ def test_encoder_multi_source_batch_equals_concat(models):
     vae.quant_conv(a[:4], out_scale=0.18215, out=cond[:, :4], channels=4)
     vae.quant_conv(a[4:8], out_scale=0.18215, out=cond[:, 4:], channels=4)
     assert torch.equal(cond[:, :4], full[:4, :4]) and torch.equal(cond[:, 4:], full[4:8, :4])
-    assert torch.equal(pipe.encode_rgb(qry), full[8:, :4])
+    # encode_rgb alone runs a batch of 2: tile plans / GroupNorm partial chunking depend on the batch size, so
+    # the same per-image arithmetic is summed in a different order -- rounding-level agreement only
+    assert rel(pipe.encode_rgb(qry), full[8:, :4]) < TOL_Z0[models["dt"]]
+
+
+def test_captured_replays_interleaved_with_plain_launches(models):
+    """The launcher's steady state: graph replay, meter-update launch, graph replay, ... with no host sync in
+    between.  (Regression: hipMemsetAsync nodes inside the captured step picked up the arguments of the plain
+    launch that followed the previous replay -- the library now zeroes its scratch words with its own kernel.)"""
+    from diffews_amd.metrics import AverageMeter, fold_class_ids
+    pipe = models["pipe"]
+    sup, qry, msk = (t.cuda() for t in _episode(2, 1, 64, seed=21))
+    gt = (torch.rand(2, 64, 64) > 0.5).to(torch.uint8).cuda()
+    cls = torch.tensor([0, 4]).cuda()
+    want = pipe.run_episodes(sup, qry, msk, gt, captured=False)["counts"].clone()
+    meter = AverageMeter("coco", fold_class_ids("coco", 0), device="cuda")
+    n = 6
+    for _ in range(n):
+        r = pipe.run_episodes(sup, qry, msk, gt, captured=True)
+        meter.update_from_counts(r["counts"], cls)
+    torch.cuda.synchronize()
+    assert torch.equal(r["counts"], want)
+    assert meter.intersection_buf[:, [0, 4]].t().tolist() == (n * want[:, 0:2]).tolist()
+    assert meter.union_buf[:, [0, 4]].t().tolist() == (n * want[:, 2:4]).tolist()

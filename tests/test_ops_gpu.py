@@ -485,3 +485,18 @@ def test_seg_postprocess_threshold_modes(ops):
     assert c_fix.cpu().tolist() == counts_of(pred_t.mean(dim=1) > 0.4)
     with pytest.raises(RuntimeError):
         ops.seg_postprocess(x.cuda(), gt.cuda(), 0.0, threshold=0.0)
+
+
+def test_meter_update_kernel_equals_index_add(ops):
+    """dfw_meter_update == AverageMeter.update's index_add_ (logger.py:35-37), repeated classes included."""
+    from diffews_amd.metrics import AverageMeter, fold_class_ids
+    g = torch.Generator().manual_seed(1)
+    a = AverageMeter("coco", fold_class_ids("coco", 0), device="cuda")
+    b = AverageMeter("coco", fold_class_ids("coco", 0), device="cpu")
+    for _ in range(5):
+        counts = torch.randint(0, 300000, (6, 4), generator=g, dtype=torch.int64)
+        cls = torch.tensor([0, 4, 4, 76, 8, 0])
+        a.update_from_counts(counts.cuda(), cls.cuda())
+        b.update(counts[:, 0:2].t(), counts[:, 2:4].t(), cls)
+    assert torch.equal(a.intersection_buf.cpu(), b.intersection_buf) and torch.equal(a.union_buf.cpu(), b.union_buf)
+    assert float(a.compute_iou()[0]) == float(b.compute_iou()[0])
