@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("stride", _i32), ("pad", _i32), ("ups", _i32), ("rows_per_img", _i32),
                 ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),
                 ("batch", _i32), ("strideA", _i64), ("strideW", _i64), ("strideC", _i64), ("dtype", _i32),
-                ("gn_partial", _vp), ("gn_groups", _i32), ("gn_in_coef", _vp), ("gn_in_silu", _i32)]
+                ("gn_partial", _vp), ("gn_groups", _i32), ("gn_in_coef", _vp), ("gn_in_silu", _i32),
+                ("colscale", _f32), ("colscale_n", _i32)]
 
 
 class FsaArgs(C.Structure):
@@ -32,7 +33,7 @@ class FsaArgs(C.Structure):
                 ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32), ("n_bank", _i32), ("nshot", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldkb", _i32), ("ldvb", _i32), ("ldo", _i32),
                 ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("kb_bs", _i64), ("vb_bs", _i64), ("o_bs", _i64),
-                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32)]
+                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32), ("q_prescaled", _i32)]
 
 
 class XattnArgs(C.Structure):

@@ -33,6 +33,11 @@ def _stale():
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
+    if os.environ.get("DFW_NO_BUILD"):
+        # e.g. under rocprofv3: the profiler's preloaded library has already initialised the GPU, and hipcc
+        # children must not be started from such a process -- a stale library is an error there, not a rebuild
+        raise RuntimeError(f"{LIB} is missing or older than its sources and DFW_NO_BUILD is set: "
+                           "run `python -m diffews_amd.build` first")
     hipcc = os.environ.get("HIPCC", "hipcc")
     objs = []
     procs = []

@@ -35,6 +35,7 @@ struct FsaP {
   int ldq, ldk, ldv, ldkb, ldvb, ldo;
   long long q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs;
   float c;  // scale * log2(e)
+  int pre;  // q already carries c (dfw_fsa_args.q_prescaled)
 };
 
 template <typename T>
@@ -289,7 +290,11 @@ __global__ __launch_bounds__(256) void fsa_kernel(const FsaP p) {
 //     inline asm so three tiles stay in flight across the barriers (counted s_waitcnt vmcnt);
 //   * the bank swizzles are applied on the DMA source address (LDS is written linearly);
 //   * one barrier per key tile, no register staging, no ds_write.
-template <typename T, int NW, int QB>
+// PRE: q arrives multiplied by scale * log2(e) (the QKV projection's epilogue did it in fp32 before its single
+// rounding), so a score needs no multiply, and the running reference maximum rides in as the INITIAL VALUE of
+// the S^T accumulators (S'' = q.k - m_ref comes straight out of the MFMA chain): on a tile that does not move
+// the reference the softmax is max3 + exp2 + add + cvt per element pair -- no fma, no subtract.
+template <typename T, int NW, int QB, bool PRE>
 __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 ? 2 : 4) * NW / 8 : 1) void fsa_ring_kernel(const FsaP p) {
   // QB = 32-row query blocks per wave: with QB = 2 the two blocks are independent dependency chains
   // in one instruction stream, so one block's softmax VALU work overlaps the other's MFMAs, and
@@ -424,15 +429,18 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   int c_tt = 0, c_own = 1;  // compute-side tile-in-segment / own-segment flag
   typename Tr<T>::v8 pf[QB][4];   // P^T fragments of the tile between its softmax and its P.V
-  auto qk_softmax = [&](const char* kbuf, int nvalid) __attribute__((always_inline)) {
+  auto qk_softmax = [&](const char* kbuf, int nvalid, bool first) __attribute__((always_inline)) {
     // ---- S^T = K . Q^T  (each K fragment feeds QB MFMAs)
     f32x16 s[QB][2];
 #pragma unroll
-    for (int g = 0; g < QB; ++g)
+    for (int g = 0; g < QB; ++g) {
+      // PRE: accumulators start at -m_ref (0 on the first tile, whose maximum becomes the reference)
+      const float init = (PRE && !first) ? -m_run[g] : 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[g][kb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[g][kb][r] = init;
+    }
     if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -461,6 +469,41 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[g][kb][r]);
       mt = half_swap_max(mt);
+      float psum = 0.f;
+      if constexpr (PRE) {
+        // mt = (row maximum of this tile) - m_ref, in log2 units.  Deferred rescale as below: the reference
+        // moves only when some row's maximum has grown past it by more than kDefer; the first tile sets it.
+        // Decided before this tile's P exists and after the previous tile's P.V: O, l and P share one scale.
+        if (first || __builtin_amdgcn_ballot_w64(mt > kDefer) != 0) {
+          const float d = first ? mt : fmaxf(mt, 0.f);       // every lane moves to its own true maximum
+          m_run[g] = first ? mt : m_run[g] + d;
+          if (!first) {
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l_run[g] *= alpha;
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[g][dd][r] *= alpha;
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = __builtin_amdgcn_exp2f(s[g][kb][r] - d);
+              s[g][kb][r] = e;
+              psum += e;
+            }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = __builtin_amdgcn_exp2f(s[g][kb][r]);
+              s[g][kb][r] = e;
+              psum += e;
+            }
+        }
+      } else {
       // Deferred rescale: O and l keep their reference maximum m_run until some row's maximum has
       // grown by more than kDefer (log2 units), so the O-wide multiply runs on a few tiles instead of
       // every tile; until then this tile's P is simply bounded by 2^kDefer instead of 1 (exact in
@@ -478,7 +521,6 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
           for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha;
       }
       const float mc = m_run[g] * p.c;
-      float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -487,6 +529,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
           s[g][kb][r] = e;
           psum += e;
         }
+      }
       l_run[g] += psum;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -553,12 +596,12 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
         bar();
         const char* kbuf = smem + (t & (S - 1)) * STAGE;
         const int nvalid = next_nvalid();
-        if constexpr (!gb) qk_softmax(kbuf, nvalid);
+        if constexpr (!gb) qk_softmax(kbuf, nvalid, t == 0);
         else if (t > 0) pv(vprev);
         bar();
         if (issued < ntiles) { issue(issued & (S - 1)); ++issued; }
         if constexpr (!gb) pv(kbuf + TILE);
-        else qk_softmax(kbuf, nvalid);
+        else qk_softmax(kbuf, nvalid, t == 0);
         vprev = kbuf + TILE;
       }
       bar();
@@ -573,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
       if (issued < ntiles) { issue(issued & (S - 1)); ++issued; }
       const char* kbuf = smem + (t & (S - 1)) * STAGE;
       const int nvalid = next_nvalid();
-      qk_softmax(kbuf, nvalid);
+      qk_softmax(kbuf, nvalid, t == 0);
       pv(kbuf + TILE);
     }
   }
@@ -699,10 +742,11 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldkb = a->ldkb; p.ldvb = a->ldvb; p.ldo = a->ldo;
   p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.kb_bs = a->kb_bs; p.vb_bs = a->vb_bs; p.o_bs = a->o_bs;
   p.c = a->scale * 1.4426950408889634f;
+  p.pre = a->q_prescaled ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   static const char* v1 = getenv("DFW_FSA_V1");
   const bool bf = a->dtype == DFW_BF16;
-  if (v1 && a->n_plain == 0) {
+  if (v1 && a->n_plain == 0 && !a->q_prescaled) {
     dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
     if (bf) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);
@@ -710,17 +754,20 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
     static const char* var = getenv("DFW_FSA_VARIANT");   // experiments: "8x1", "4x2", "4x1"
     int nw = 8, qb = 1;
     if (var) sscanf(var, "%dx%d", &nw, &qb);
+    qb = 1;   // the two-query-block variant was an experiment (never faster); one block per wave everywhere
     if (a->n_q <= 1024 && !var) { nw = 4; qb = 1; }   // short rows: 128-query workgroups balance the grid better (measured)
     dim3 grid((a->n_q + nw * 32 * qb - 1) / (nw * 32 * qb), a->heads, a->batch);
+    const bool pre = a->q_prescaled != 0;
     if (nw == 8) {
-      if (bf) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 8, 1>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 8, 1>), grid, dim3(512), 0, st, p);
-    } else if (qb == 2) {
-      if (bf) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 4, 2>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 4, 2>), grid, dim3(256), 0, st, p);
+      if (bf) { if (pre) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 8, 1, true>), grid, dim3(512), 0, st, p);
+                else hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 8, 1, false>), grid, dim3(512), 0, st, p); }
+      else { if (pre) hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 8, 1, true>), grid, dim3(512), 0, st, p);
+             else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 8, 1, false>), grid, dim3(512), 0, st, p); }
     } else {
-      if (bf) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 4, 1>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 4, 1>), grid, dim3(256), 0, st, p);
+      if (bf) { if (pre) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 4, 1, true>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 4, 1, false>), grid, dim3(256), 0, st, p); }
+      else { if (pre) hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 4, 1, true>), grid, dim3(256), 0, st, p);
+             else hipLaunchKernelGGL((fsa_ring_kernel<_Float16, 4, 1, false>), grid, dim3(256), 0, st, p); }
     }
   }
   DFW_CHECK_LAUNCH();

@@ -413,7 +413,7 @@ static bool halo_shape_ok(const GemmP& p, int& bn) {
   if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.ups) return false;
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Ho % 16) != 0 || (p.Wo % 16) != 0) return false;
   if (p.splitk > 1 || p.batch > 1 || (p.N % 128) != 0 || (p.Cin % 64) != 0) return false;
-  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu) return false;
+  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0) return false;
   if (p.M % 256 != 0 || p.rows_per_img != p.Ho * p.Wo) return false;
   bn = (p.N % 256) == 0 ? 256 : 128;
   return (long long)(p.M / 256) * (p.N / bn) >= 192;

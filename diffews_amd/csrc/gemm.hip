@@ -447,6 +447,8 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.ldrb = a->ld_rowbias > 0 ? a->ld_rowbias : a->N;
   p.taps = a->taps; p.Cin = a->Cin; p.Hi = a->Hi; p.Wi = a->Wi; p.Ho = a->Ho; p.Wo = a->Wo;
   p.stride = a->stride; p.pad = a->pad; p.ups = a->ups; p.rows_per_img = rpi;
+  if (a->colscale_n < 0 || (a->colscale_n % 64) != 0 || a->colscale_n > a->N || (a->colscale_n > 0 && a->geglu)) return DFW_ESHAPE;
+  p.cs = a->colscale; p.cs_n = a->colscale_n;
   p.out_scale = a->out_scale; p.act = a->act; p.geglu = a->geglu; p.out_mode = a->out_mode;
   p.splitk = splitk; p.batch = batch;
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;

@@ -257,8 +257,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
         for (int g = 0; g < 4; ++g) {
           float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
           if (p.residual) unpack4<T>(res[j][g], r);
+          const float osc = (c.n0 + wn * 64 + j * 32 + 8 * g + 4 * lh) < p.cs_n ? p.cs : p.out_scale;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + add[j][g][e] + r[e]) * p.out_scale;
+          for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + add[j][g][e] + r[e]) * osc;
           const int c16 = j * 4 + g;  // 16-byte chunk of the wave tile's 128-byte row
           *(i32x2*)(stg + lr * 128 + ((c16 ^ (lr & 7)) << 4) + lh * 8) = pack4<T>(v);
         }
@@ -437,6 +438,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
             if (p.residual && m < p.M) res[h][j] = *(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T));
           }
         }
+        float osc6[NB6];
+#pragma unroll
+        for (int j = 0; j < NB6; ++j) osc6[j] = (c.n0 + wn * 64 + j * 16 + 4 * l4) < p.cs_n ? p.cs : p.out_scale;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
             float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) unpack4<T>(res[h][j], r);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (acc6[2 * i + h][j][e] + add[h][j][e] + r[e]) * p.out_scale;
+            for (int e = 0; e < 4; ++e) v[e] = (acc6[2 * i + h][j][e] + add[h][j][e] + r[e]) * osc6[j];
             const int row = h * 16 + l15, quad = j * 4 + l4;   // 8-byte piece `quad` of the staged 128-byte row
             *(i32x2*)(stg + row * 128 + (((quad >> 1) ^ (row & 7)) << 4) + (quad & 1) * 8) = pack4<T>(v);
           }

@@ -12,6 +12,7 @@ struct GemmP {
   int M, N, K, lda, ldc, ldr, ldrb;
   int taps, Cin, Hi, Wi, Ho, Wo, stride, pad, ups, rows_per_img;
   float out_scale;
+  float cs; int cs_n;   // output columns n < cs_n are scaled by cs instead of out_scale (0: none)
   int act, geglu, out_mode, splitk, batch;
   long long strideA, strideW, strideC;
   int nk, cpt, ntn, ntm;
@@ -54,7 +55,7 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    v[i] *= p.out_scale;
+    v[i] *= (n < p.cs_n ? p.cs : p.out_scale);
     if (p.act == DFW_ACT_SILU) v[i] = silu_f(v[i]);
     else if (p.act == DFW_ACT_CLAMP1) v[i] = fminf(fmaxf(v[i], -1.0f), 1.0f);
   }
@@ -116,7 +117,7 @@ __device__ __forceinline__ void epi_block(const GemmP& p, char* Cb, int m, int i
       if (p.residual) unpack4<T>(res[j][g], r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = (a[j][4 * g + e] + add[j][g][e] + r[e]) * p.out_scale;
+        v[e] = (a[j][4 * g + e] + add[j][g][e] + r[e]) * (n < p.cs_n ? p.cs : p.out_scale);
         if (!SLIM && p.act == DFW_ACT_SILU) v[e] = silu_f(v[e]);
         else if (!SLIM && p.act == DFW_ACT_CLAMP1) v[e] = fminf(fmaxf(v[e], -1.0f), 1.0f);
       }

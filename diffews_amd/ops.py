@@ -75,8 +75,9 @@ def _gemm_launch(lib, a):
 
 
 def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.ACT_NONE, geglu=False,
-           out=None, out_f32=False, out_scale=1.0, splitk=None):
-    """y[M, N] = epi(x[M, K] @ w[N, K]^T).  x may be a row-strided view ([M, K] with stride (ld, 1))."""
+           out=None, out_f32=False, out_scale=1.0, splitk=None, colscale=None):
+    """y[M, N] = epi(x[M, K] @ w[N, K]^T).  x may be a row-strided view ([M, K] with stride (ld, 1)).
+    colscale = (n, s): output columns < n (a multiple of 64) are multiplied by s in fp32 before rounding."""
     assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.is_contiguous()
     M, K = x.shape
     N = w.shape[0]
@@ -101,6 +102,8 @@ def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.A
     a.out_mode = L.OUT_F32 if out.dtype == torch.float32 else L.OUT_T
     a.splitk = 0 if splitk is None else splitk   # 0: the library plans tile + split-K
     a.batch, a.dtype = 1, _dt(x)
+    if colscale is not None:
+        a.colscale_n, a.colscale = int(colscale[0]), float(colscale[1])
     _gemm_call(a)
     return out
 
@@ -205,10 +208,12 @@ def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
     return L.lib().dfw_gemm_gn_input_ok(C.byref(a)) == 1
 
 
-def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None, n_plain=0):
+def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None, n_plain=0,
+                  q_prescaled=False):
     """KV-fusion self-attention.  q/k/v: [B, N, heads*64] views (token stride = stride(1));
     k_bank/v_bank: [(B-n_plain)*nshot, Nb, heads*64] views written by the support pass.
-    n_plain: the first n_plain batch entries ignore the bank (lock-step [support ; query] launch)."""
+    n_plain: the first n_plain batch entries ignore the bank (lock-step [support ; query] launch).
+    q_prescaled: q already carries scale * log2(e) (linear(..., colscale=(C, FSA_QSCALE)))."""
     B, N, Cq = q.shape
     assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
@@ -226,7 +231,7 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
         a.n_bank, a.nshot = k_bank.shape[1], nshot
         a.ldkb, a.ldvb, a.kb_bs, a.vb_bs = k_bank.stride(1), v_bank.stride(1), k_bank.stride(0), v_bank.stride(0)
     a.scale = scale if scale is not None else 64 ** -0.5
-    a.dtype, a.n_plain = _dt(q), n_plain
+    a.dtype, a.n_plain, a.q_prescaled = _dt(q), n_plain, int(bool(q_prescaled))
     if gemm_hook is not None:   # bench.py roofline leg: QK^T + PV flops of this launch
         keys = n_plain * k.shape[1] + (B - n_plain) * (k.shape[1] + (nshot * k_bank.shape[1] if nshot else 0))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -237,6 +242,9 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
         return out
     L.check(L.lib().dfw_fsa_attention(C.byref(a), _stream()), "dfw_fsa_attention")
     return out
+
+
+FSA_QSCALE = 64 ** -0.5 * math.log2(math.e)   # attn.scale (A:269-271, head_dim 64) in exp2 units
 
 
 def cross_attention(q, k, v, heads, scale=None):

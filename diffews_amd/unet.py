@@ -147,7 +147,9 @@ class _Transformer:
         t = ops.linear(n.view(-1, C), self.w_in, bias=self.b_in)
         # --- attn1: KV-fusion self-attention (A:237-271)
         ln = ops.layernorm(t, *self.ln[0])
-        qkv = ops.linear(ln, self.w_qkv).view(B, N, 3 * C)
+        # q leaves the projection multiplied by attn.scale * log2(e) (fp32, before its one rounding): the
+        # attention kernel then exponentiates q.k - m directly; k and v (the bank, A:251-267) are untouched
+        qkv = ops.linear(ln, self.w_qkv, colscale=(C, ops.FSA_QSCALE)).view(B, N, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         if n_ref:
             bq = B - n_ref
@@ -155,15 +157,16 @@ class _Transformer:
                 raise ValueError(f"{n_ref} support images is not a multiple of the {bq} query images")
             # one launch for both passes: support images attend over their own keys, query images over
             # [own ; their episode's support images]; long (query) workgroups are dispatched first
-            att = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=n_ref // bq, n_plain=n_ref)
+            att = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=n_ref // bq, n_plain=n_ref,
+                                    q_prescaled=True)
         elif self.k_bank is None:  # A:251-252 / 260-261: first pass after clear fills the bank
             self.k_bank, self.v_bank = k, v
-            att = ops.fsa_attention(q, k, v, heads)
+            att = ops.fsa_attention(q, k, v, heads, q_prescaled=True)
         else:                    # A:253-258 / 262-267: [own ; bank], ref batch folded into tokens
             bank_b = self.k_bank.shape[0]
             if bank_b % B != 0:
                 raise ValueError(f"bank holds {bank_b} support images, not a multiple of the query batch {B}")
-            att = ops.fsa_attention(q, k, v, heads, self.k_bank, self.v_bank, nshot=bank_b // B)
+            att = ops.fsa_attention(q, k, v, heads, self.k_bank, self.v_bank, nshot=bank_b // B, q_prescaled=True)
         t = ops.linear(att.view(-1, C), self.w_o1, bias=self.b_o1, residual=t)
         # --- attn2: cross-attention on the prompt tokens
         ln = ops.layernorm(t, *self.ln[1])

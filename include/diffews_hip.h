@@ -85,6 +85,11 @@ typedef struct {
    * U:963-1012 and by the VAE) cost no HBM pass.  Only where dfw_gemm_gn_input_ok() returns 1;
    * dfw_gemm fails with DFW_ESHAPE otherwise. */
   const float* gn_in_coef; int32_t gn_in_silu;
+  /* Optional: output columns n < colscale_n (a multiple of 64) are multiplied by `colscale` instead of
+   * out_scale, in fp32 before the single rounding to the storage dtype.  The fused [Wq;Wk;Wv] projection
+   * (A:237-245) uses it to hand the attention kernel q * (scale * log2 e): the softmax then needs no
+   * multiply per score (dfw_fsa_args.q_prescaled). */
+  float colscale; int32_t colscale_n;
 } dfw_gemm_args;
 
 int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);
@@ -120,6 +125,9 @@ typedef struct {
    * b >= n_plain is episode b - n_plain and reads bank images (b - n_plain)*nshot + shot.  0 = every
    * entry reads the bank (the two-pass form). */
   int32_t n_plain;
+  /* != 0: q already carries the factor scale * log2(e) (dfw_gemm_args.colscale on the projection that
+   * produced it); `scale` is then ignored and the kernel exponentiates with exp2(q.k - m) directly. */
+  int32_t q_prescaled;
 } dfw_fsa_args;
 
 int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream);

@@ -6,6 +6,8 @@
 set -e -o pipefail
 ROUND=${1:-r02}
 REPO=$(pwd)
+python3 -m diffews_amd.build > /dev/null      # never rebuild under the profiler (DFW_NO_BUILD below)
+export DFW_NO_BUILD=1
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph"
 for C in FETCH_SIZE WRITE_SIZE; do

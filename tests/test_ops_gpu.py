@@ -229,16 +229,31 @@ def test_conv3x3_small_cout_nchw(ops, dtype, Cout):
     assert y.shape == ref.shape and rel(y, ref) < 2e-5
 
 
+def _prescale(q, pre):
+    """pre: (q handed to the kernel already multiplied by attn.scale * log2 e and rounded once, the q the
+    reference must then be computed from) -- the kernel's input is what it is judged on."""
+    if not pre:
+        return q, q.float()
+    from diffews_amd.ops import FSA_QSCALE
+    q_in = (q.float() * FSA_QSCALE).to(q.dtype)
+    return q_in, q_in.float() / FSA_QSCALE
+
+
+PRE = [False, True]
+
+
+@pytest.mark.parametrize("pre", PRE, ids=["scale_in_kernel", "q_prescaled"])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,heads,N,nshot", [(1, 1, 64, 0), (2, 2, 256, 0), (2, 2, 256, 1), (1, 5, 200, 2),
                                              (2, 1, 16, 3), (1, 2, 1024, 1), (2, 3, 100, 0)])
-def test_fsa_attention(ops, dtype, B, heads, N, nshot):
+def test_fsa_attention(ops, dtype, B, heads, N, nshot, pre):
     """Empty bank == plain SDPA; with a bank == SDPA over [own ; shot0 ; shot1 ...] per episode
     (attention_processor.py:256-258: ref image = episode*nshot + shot)."""
     C = heads * 64
     qkv = rnd((B, N, 3 * C), dtype, 1)
     bank = rnd((max(B * nshot, 1), N, 3 * C), dtype, 2)
     q, k, v = qkv.float().split(C, dim=-1)
+    q_in, q = _prescale(qkv[..., :C], pre)
     if nshot:
         kb, vb = bank.float()[..., C:2 * C], bank.float()[..., 2 * C:]
         k = torch.cat([k, kb.reshape(B, nshot * N, C)], dim=1)
@@ -246,36 +261,41 @@ def test_fsa_attention(ops, dtype, B, heads, N, nshot):
     sh = lambda t: t.reshape(B, -1, heads, 64).transpose(1, 2)
     ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v)).transpose(1, 2).reshape(B, N, C)
     qg, bg = qkv.cuda(), bank.cuda()
-    y = ops.fsa_attention(qg[..., :C], qg[..., C:2 * C], qg[..., 2 * C:], heads,
+    y = ops.fsa_attention(q_in.cuda(), qg[..., C:2 * C], qg[..., 2 * C:], heads,
                           k_bank=bg[..., C:2 * C] if nshot else None, v_bank=bg[..., 2 * C:] if nshot else None,
-                          nshot=nshot)
+                          nshot=nshot, q_prescaled=pre)
     assert rel(y, ref) < 1.5 * TOL[dtype]  # + P rounded to the storage dtype before PV
 
 
+@pytest.mark.parametrize("pre", PRE, ids=["scale_in_kernel", "q_prescaled"])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_fsa_attention_online_softmax_rescale(ops, dtype):
+def test_fsa_attention_online_softmax_rescale(ops, dtype, pre):
     """Force the running-max rescale branch: one late key dominates each query row."""
     B, heads, N = 1, 1, 256
     C = 64
     q, k, v = rnd((B, N, C), dtype, 1), rnd((B, N, C), dtype, 2), rnd((B, N, C), dtype, 3)
     k[0, 200] = q[0, 17] * 4  # spike in the 4th key tile
     k[0, 70] = q[0, 100] * 3
-    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
-    y = ops.fsa_attention(q.cuda(), k.cuda(), v.cuda(), heads)
+    q, qr = _prescale(q, pre)
+    ref = F.scaled_dot_product_attention(qr[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    y = ops.fsa_attention(q.cuda(), k.cuda(), v.cuda(), heads, q_prescaled=pre)
     assert rel(y, ref) < 1.5 * TOL[dtype]
     assert rel(y[0, 17], ref[0, 17]) < 3 * TOL[dtype]
 
 
+@pytest.mark.parametrize("pre", PRE, ids=["scale_in_kernel", "q_prescaled"])
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("step", [0.5, 2.0, 5.0, 12.0])
-def test_fsa_attention_deferred_rescale_ramp(ops, dtype, step):
+@pytest.mark.parametrize("step", [0.5, 2.0, 5.0, 12.0, -3.0])
+def test_fsa_attention_deferred_rescale_ramp(ops, dtype, step, pre):
     """The kernel rescales O / l only when a row's maximum grew by more than 2^8 since the last rescale
     (deferred rescale).  A bounded random test never takes either side deliberately, so build rows whose
     score maximum climbs by `step` log2-units per 64-key tile over 16 tiles: 0.5 never fires after the
-    first tile (P up to 2^8 at the old scale), 2.0 fires every 5th tile, 5.0 every 2nd, 12.0 every tile --
-    and per row, every element must still match (a mis-ordered rescale corrupts only the rows that grew)."""
+    first tile (P up to 2^8 at the old scale), 2.0 fires every 5th tile, 5.0 every 2nd, 12.0 every tile,
+    -3.0 is a FALLING ramp (the first tile holds the maximum, later tiles sink 45 log2-units below the
+    reference) -- and per row, every element must still match (a mis-ordered rescale corrupts only the rows
+    that grew).  q_prescaled exercises the accumulator-initialised reference maximum of the same kernel."""
     B, heads, N, C = 1, 1, 1024, 64
-    g = torch.Generator().manual_seed(int(step * 10))
+    g = torch.Generator().manual_seed(int(abs(step) * 10))
     q = torch.randn(B, N, C, generator=g)
     q = q / q.norm(dim=-1, keepdim=True) * 8.0
     k = torch.randn(B, N, C, generator=g) * 0.05
@@ -290,27 +310,33 @@ def test_fsa_attention_deferred_rescale_ramp(ops, dtype, step):
     half = (N // 2)
     k[0, half:, 0] = k[0, half:, 0].flip(0) if step == 5.0 else k[0, half:, 0]   # also a falling tail
     q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
-    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
-    y = ops.fsa_attention(q.cuda(), k.cuda(), v.cuda(), heads).float().cpu()
+    q, qr = _prescale(q, pre)
+    ref = F.scaled_dot_product_attention(qr[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    y = ops.fsa_attention(q.cuda(), k.cuda(), v.cuda(), heads, q_prescaled=pre).float().cpu()
     assert rel(y, ref) < 1.5 * TOL[dtype]
     row_err = (y - ref).norm(dim=-1) / (ref.norm(dim=-1) + 1e-6)
     assert float(row_err.max()) < 6 * TOL[dtype], float(row_err.max())
 
 
+@pytest.mark.parametrize("pre", PRE, ids=["scale_in_kernel", "q_prescaled"])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("b,nshot,heads,N", [(2, 1, 2, 256), (1, 3, 1, 192), (3, 2, 2, 100)])
-def test_fsa_attention_lockstep_launch(ops, dtype, b, nshot, heads, N):
+def test_fsa_attention_lockstep_launch(ops, dtype, b, nshot, heads, N, pre):
     """n_plain: ONE launch over [support images ; query images] == the bank-fill launch on the support
     images followed by the bank-reading launch on the queries (A:251-267), bit for bit, and == SDPA."""
     C = heads * 64
     n_ref = b * nshot
     qkv = rnd((n_ref + b, N, 3 * C), dtype, 11).cuda()
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    q, qr = _prescale(q, pre)
+    q, qr = q.contiguous(), qr.cuda()
     two = torch.empty(n_ref + b, N, C, dtype=dtype, device="cuda")
-    ops.fsa_attention(q[:n_ref], k[:n_ref], v[:n_ref], heads, out=two[:n_ref])
-    ops.fsa_attention(q[n_ref:], k[n_ref:], v[n_ref:], heads, k[:n_ref], v[:n_ref], nshot=nshot, out=two[n_ref:])
-    one = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=nshot, n_plain=n_ref)
+    ops.fsa_attention(q[:n_ref], k[:n_ref], v[:n_ref], heads, out=two[:n_ref], q_prescaled=pre)
+    ops.fsa_attention(q[n_ref:], k[n_ref:], v[n_ref:], heads, k[:n_ref], v[:n_ref], nshot=nshot, out=two[n_ref:],
+                      q_prescaled=pre)
+    one = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=nshot, n_plain=n_ref, q_prescaled=pre)
     assert torch.equal(one, two)
+    q = qr
     sh = lambda t: t.float().reshape(t.shape[0], -1, heads, 64).transpose(1, 2)
     kq = torch.cat([k[n_ref:], k[:n_ref].reshape(b, nshot * N, C)], dim=1)
     vq = torch.cat([v[n_ref:], v[:n_ref].reshape(b, nshot * N, C)], dim=1)
@@ -500,3 +526,21 @@ def test_meter_update_kernel_equals_index_add(ops):
         b.update(counts[:, 0:2].t(), counts[:, 2:4].t(), cls)
     assert torch.equal(a.intersection_buf.cpu(), b.intersection_buf) and torch.equal(a.union_buf.cpu(), b.union_buf)
     assert float(a.compute_iou()[0]) == float(b.compute_iou()[0])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_column_scale(ops, dtype):
+    """colscale: the first n output columns (the q third of the fused [Wq;Wk;Wv] projection) leave the epilogue
+    multiplied by s in fp32 BEFORE the single rounding; the other columns are untouched.  Every GEMM kernel
+    family that serves a QKV projection: 64x64-level rows (gemm_big) and short / ragged row counts (gemm.hip)."""
+    from diffews_amd.ops import FSA_QSCALE
+    for M, C in [(32768, 320), (8192, 640), (2048, 1280), (300, 64), (512, 1280)]:
+        x, w = rnd((M, C), dtype, 1), rnd((3 * C, C), dtype, 2, C ** -0.5)
+        ref = x.float() @ w.float().t()
+        ref[:, :C] *= FSA_QSCALE
+        y = ops.linear(x.cuda(), w.cuda(), colscale=(C, FSA_QSCALE))
+        assert rel(y[:, :C], ref[:, :C]) < TOL[dtype] and rel(y[:, C:], ref[:, C:]) < TOL[dtype], (M, C)
+        # same bits as scaling a wider-precision result: compare with the fp32-output GEMM scaled on the host
+        y32 = ops.linear(x.cuda(), w.cuda(), out_f32=True).cpu()
+        y32[:, :C] *= FSA_QSCALE
+        assert torch.equal(y.cpu(), y32.to(dtype)), (M, C)
