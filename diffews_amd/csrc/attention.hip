@@ -454,6 +454,10 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
 #pragma unroll
     for (int g = 0; g < QB; ++g) {
       if (nvalid < KT) {
+        // ragged last tile of a key segment only.  The empty asm keeps this a REAL (scalar) branch: hipcc
+        // otherwise if-converts the body into 32 v_cmp + 32 v_cndmask + the key-index arithmetic executed on
+        // EVERY tile -- ~100 VALU instructions, as many issue cycles as the whole softmax.
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -572,8 +576,12 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  // segment lengths pinned in SGPRs: left to the compiler, `c_own ? p.n_kv : p.n_bank` became a scalar LOAD from
+  // a selected kernarg address plus s_waitcnt lgkmcnt(0) at the head of every tile
+  int seg_nkv = p.n_kv, seg_nbank = p.n_bank;
+  asm volatile("" : "+s"(seg_nkv), "+s"(seg_nbank));
   auto next_nvalid = [&]() __attribute__((always_inline)) {
-    const int nv = (c_own ? p.n_kv : p.n_bank) - c_tt * KT;
+    const int nv = (c_own ? seg_nkv : seg_nbank) - c_tt * KT;
     if (++c_tt == (c_own ? tiles_own : tiles_bank)) { c_tt = 0; c_own = 0; }
     return nv;
   };

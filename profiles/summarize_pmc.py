@@ -26,6 +26,9 @@ def readable(mangled):
     m = re.search(r"gemm_kernelIDF16(b|_)Li(\d+)ELi(\d+)ELb(\d)", mangled)
     if m:
         return f"gemm_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},{m.group(2)},{m.group(3)},{'conv' if m.group(4) == '1' else 'lin'}>"
+    m = re.search(r"fsa_ring_kernelIDF16(b|_)Li(\d+)ELi(\d+)ELb(\d)", mangled)
+    if m:
+        return f"fsa_ring_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},{m.group(2)},{m.group(3)},{'pre' if m.group(4) == '1' else 'scale'}>"
     m = re.search(r"dfw\d+([a-z_0-9]+?)I", mangled)
     return m.group(1) if m else mangled[:60]
 
