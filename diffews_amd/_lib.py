@@ -33,7 +33,7 @@ class FsaArgs(C.Structure):
                 ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32), ("n_bank", _i32), ("nshot", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldkb", _i32), ("ldvb", _i32), ("ldo", _i32),
                 ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("kb_bs", _i64), ("vb_bs", _i64), ("o_bs", _i64),
-                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32), ("q_prescaled", _i32)]
+                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32), ("q_prescaled", _i32), ("lse", _vp)]
 
 
 class XattnArgs(C.Structure):
@@ -69,6 +69,41 @@ class ImageArgs(C.Structure):
                 ("tmp", _vp), ("dst", _vp), ("lut", _vp)]
 
 
+class GemmTnArgs(C.Structure):
+    _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("workspace", _vp), ("workspace_bytes", _sz),
+                ("a_elems", _i64), ("b_elems", _i64),
+                ("M", _i32), ("N", _i32), ("Kc", _i32), ("lda", _i32), ("ldb", _i32),
+                ("taps", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32), ("stride", _i32), ("pad", _i32), ("ups", _i32),
+                ("batch", _i32), ("batch2", _i32), ("strideA", _i64), ("strideB", _i64), ("strideA2", _i64), ("strideB2", _i64),
+                ("ldo_n", _i64), ("ldo_t", _i64), ("ldo_b", _i64), ("scale", _f32), ("accumulate", _i32), ("dtype", _i32)]
+
+
+class GroupNormBwdArgs(C.Structure):
+    _fields_ = [("x", _vp), ("dy", _vp), ("dx", _vp), ("gamma", _vp), ("beta", _vp), ("mean_rstd", _vp),
+                ("dgamma", _vp), ("dbeta", _vp), ("workspace", _vp), ("workspace_bytes", _sz),
+                ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("ldx", _i32), ("lddy", _i32), ("lddx", _i32),
+                ("silu", _i32), ("accumulate", _i32), ("grad_scale", _f32), ("dtype", _i32)]
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [("x", _vp), ("dy", _vp), ("dx", _vp), ("gamma", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("workspace", _vp), ("workspace_bytes", _sz),
+                ("rows", _i32), ("C", _i32), ("ldx", _i32), ("lddy", _i32), ("lddx", _i32), ("eps", _f32),
+                ("accumulate", _i32), ("grad_scale", _f32), ("dtype", _i32)]
+
+
+class FsaBwdArgs(C.Structure):
+    _fields_ = [("qkv", _vp), ("out", _vp), ("dout", _vp), ("lse", _vp), ("delta", _vp), ("dqkv", _vp),
+                ("batch", _i32), ("heads", _i32), ("n", _i32), ("nshot", _i32), ("n_plain", _i32),
+                ("ld", _i32), ("ldo", _i32), ("ldd", _i32), ("scale", _f32), ("dtype", _i32)]
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_sumsq", _vp), ("n", _i64),
+                ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_grad_norm", _f32),
+                ("step", _i32)]
+
+
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dfw_version": (_i32, []),
@@ -93,6 +128,21 @@ SYMBOLS = {
     "dfw_seg_postprocess": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "dfw_seg_postprocess_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     "dfw_meter_update": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "dfw_gemm_tn": (_i32, [C.POINTER(GemmTnArgs), _vp]),
+    "dfw_gemm_tn_workspace_bytes": (_sz, [C.POINTER(GemmTnArgs)]),
+    "dfw_colsum": (_i32, [_vp, _vp, _vp, _sz, _i64, _i32, _i32, _i32, _i64, _f32, _i32, _i32, _vp]),
+    "dfw_colsum_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "dfw_groupnorm_bwd": (_i32, [C.POINTER(GroupNormBwdArgs), _vp]),
+    "dfw_groupnorm_bwd_workspace_bytes": (_sz, [C.POINTER(GroupNormBwdArgs)]),
+    "dfw_layernorm_bwd": (_i32, [C.POINTER(LayerNormBwdArgs), _vp]),
+    "dfw_layernorm_bwd_workspace_bytes": (_sz, [_i32, _i32]),
+    "dfw_geglu": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "dfw_elementwise": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dfw_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dfw_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dfw_fsa_attention_bwd": (_i32, [C.POINTER(FsaBwdArgs), _vp]),
+    "dfw_sumsq": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "dfw_adamw": (_i32, [C.POINTER(AdamWArgs), _vp]),
     "dfw_resample_ksize": (_i32, [_i32, _i32]),
     "dfw_resample_coeffs": (_i32, [_i32, _i32, _vp, _vp]),
     "dfw_image_to_tensor": (_i32, [C.POINTER(ImageArgs), _vp]),

@@ -15,6 +15,7 @@
 //                   fragments come from the row-major V tile via ds_read_b64_tr_b16.
 // fp32 accumulation and fp32 softmax statistics throughout.
 #include "common.h"
+#include "attention_common.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
@@ -36,45 +37,8 @@ struct FsaP {
   long long q_bs, k_bs, v_bs, kb_bs, vb_bs, o_bs;
   float c;  // scale * log2(e)
   int pre;  // q already carries c (dfw_fsa_args.q_prescaled)
+  float* lse;  // optional [batch][heads][n_q]: log2-sum-exp2 of the (scaled) scores, for the backward
 };
-
-template <typename T>
-__device__ __forceinline__ typename Tr<T>::v4 lds_tr_read(const char* p);
-template <>
-__device__ __forceinline__ bf16x4 lds_tr_read<__bf16>(const char* p) {
-  using s16x4 = short __attribute__((ext_vector_type(4)));
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-  return __builtin_bit_cast(bf16x4, r);
-}
-template <>
-__device__ __forceinline__ f16x4 lds_tr_read<_Float16>(const char* p) {
-  using s16x4 = short __attribute__((ext_vector_type(4)));
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-  return __builtin_bit_cast(f16x4, r);
-}
-
-// Exchange a value with lane^32.  v_permlane32_swap swaps vdst[32..63] with src[0..31]; fed the
-// same value twice it leaves {own | low-half copy} in one register and {high-half copy | own} in
-// the other, so max/sum of the two is the cross-half reduction in every lane.
-// Written as inline asm: with the builtin, hipcc (ROCm 7.2) copy-propagates the second result
-// away when both inputs are copies of one value (r[1] is replaced by r[0]).  The s_nop covers the
-// VALU-write -> v_permlane read hazard (2 wait states), which hipcc does not pad inside asm.
-__device__ __forceinline__ void half_swap(float v, float& r0, float& r1) {
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  r0 = a;
-  r1 = b;
-}
-__device__ __forceinline__ float half_swap_max(float v) {
-  float r0, r1;
-  half_swap(v, r0, r1);
-  return fmaxf(r0, r1);
-}
-__device__ __forceinline__ float half_swap_sum(float v) {
-  float r0, r1;
-  half_swap(v, r0, r1);
-  return r0 + r1;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void fsa_kernel(const FsaP p) {
@@ -635,6 +599,8 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + g * 32 + lr;
   if (qrow < p.n_q) {
+    if (p.lse && lh == 0)   // exp2(s' - lse) is the row's probability (s' = scaled score in log2 units)
+      p.lse[((size_t)b * p.heads + head) * p.n_q + qrow] = (PRE ? m_run[g] : m_run[g] * p.c) + __builtin_amdgcn_logf(l_tot);
     char* ob = p.out + ((size_t)b * p.o_bs + (size_t)qrow * p.ldo + head * 64) * sizeof(T);
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -751,10 +717,11 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.kb_bs = a->kb_bs; p.vb_bs = a->vb_bs; p.o_bs = a->o_bs;
   p.c = a->scale * 1.4426950408889634f;
   p.pre = a->q_prescaled ? 1 : 0;
+  p.lse = a->lse;
   hipStream_t st = (hipStream_t)stream;
   static const char* v1 = getenv("DFW_FSA_V1");
   const bool bf = a->dtype == DFW_BF16;
-  if (v1 && a->n_plain == 0 && !a->q_prescaled) {
+  if (v1 && a->n_plain == 0 && !a->q_prescaled && !a->lse) {
     dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
     if (bf) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);

@@ -1,0 +1,387 @@
+// Backward of the KV-fusion self-attention (attention_processor.py:247-271 under autograd: the banks keep their
+// graph, so the query loss reaches the support pass through k_bank / v_bank, T:1374-1375), head_dim 64, for the
+// lock-step batch [support images ; query images] of dfw_fsa_args.n_plain (or plain self-attention, nshot = 0).
+//
+// Flash-style: the N x N_k probabilities are recomputed from q, k and the forward's per-row log-sum-exp instead
+// of being stored.  Two kernels, each without any cross-workgroup sum (deterministic, no atomics):
+//   fsa_bwd_dq_kernel   one workgroup = 128 query rows of one (image, head); walks that row's keys
+//                       [own ; shot 0 ; shot 1 ...] exactly like the forward:  S^T = K Q^T - lse (the row constant
+//                       rides in as the accumulator's initial value), P^T = exp2(S^T), dP^T = V dO^T - delta,
+//                       dS^T = P^T o dP^T, dQ^T += K^T dS^T.
+//   fsa_bwd_dkv_kernel  one workgroup = 128 keys of one (image, head); walks every query row that attends to them
+//                       (the image's own queries and, for a support image, its episode's query image):
+//                       S = Q K^T - lse, P = exp2(S), dP = dO V^T - delta, dS = P o dP, dV^T += dO^T P,
+//                       dK^T += Q^T dS.  K / V fragments stay in registers; the key sits on the MFMA lane, so P and
+//                       dS are used as B operands straight from the accumulators.
+// q is the PRE-SCALED query (q * scale * log2 e, dfw_gemm_args.colscale): scores are exp2 exponents.  dq is returned
+// with respect to the UNSCALED projection output (d(x Wq) = scale * dS K), dk = ln2 * dS^T q_pre, so the caller
+// backpropagates through the fused QKV Linear without special cases.
+#include "common.h"
+#include "attention_common.h"
+
+namespace dfw {
+
+struct FsaBwdP {
+  const char* q; const char* k; const char* v; const char* dout; const float* lse; const float* delta;
+  char* dq; char* dk; char* dv;
+  uint32_t qkv_bytes, do_bytes, dqkv_bytes;
+  int batch, heads, n, nshot, n_plain;
+  int ld, ldo, ldd;                       // token strides of q/k/v (one fused buffer), dout, dq/dk/dv
+  long long bs, obs, dbs;                 // image strides
+  float scale;
+};
+
+__device__ __forceinline__ uint32_t row_off(int row, int chunk) {   // K-style image: b128 row reads
+  return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+__device__ __forceinline__ uint32_t tr_off(int row, int dcol) {     // V-style image: transposed reads
+  return (uint32_t)(row * 128 + ((((dcol >> 3) ^ (((row >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1));
+}
+
+// delta[b][h][q] = sum_d dO * O   (fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_delta_kernel(const char* o, const char* dout, float* delta, int batch, int heads,
+                                                        int n, int ldo, long long obs, int ldd, long long dbs) {
+  const long long total = (long long)batch * heads * n;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int qi = (int)(e % n);
+    const long long bh = e / n;
+    const int h = (int)(bh % heads), b = (int)(bh / heads);
+    const char* po = o + ((size_t)b * obs + (size_t)qi * ldo + h * 64) * sizeof(T);
+    const char* pd = dout + ((size_t)b * dbs + (size_t)qi * ldd + h * 64) * sizeof(T);
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a[8], d[8];
+      unpack8<T>(*(const i32x4*)(po + c * 16), a);
+      unpack8<T>(*(const i32x4*)(pd + c * 16), d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += a[i] * d[i];
+    }
+    delta[e] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
+  constexpr int KT = 64, TILE = KT * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];   // [buf][K rows | K tr | V rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int bank_b = b - p.n_plain;
+  const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);        // q, k, v live in one fused buffer
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.dout, p.do_bytes);
+  const uint32_t koff = (uint32_t)((const char*)p.k - (const char*)p.q), voff = (uint32_t)((const char*)p.v - (const char*)p.q);
+
+  const int qrow = q0 + lr;
+  const bool qok = qrow < p.n;
+  typename Tr<T>::v8 qf[4], dof[4];
+  {
+    const uint32_t bq = qok ? (uint32_t)(((size_t)b * p.bs + (size_t)qrow * p.ld + head * 64 + lh * 8) * sizeof(T)) : kOOB;
+    const uint32_t bd = qok ? (uint32_t)(((size_t)b * p.obs + (size_t)qrow * p.ldo + head * 64 + lh * 8) * sizeof(T)) : kOOB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = as_v8<T>(buf_load16(rqkv, bq == kOOB ? kOOB : bq + (uint32_t)(s * 32)));
+      dof[s] = as_v8<T>(buf_load16(rdo, bd == kOOB ? kOOB : bd + (uint32_t)(s * 32)));
+    }
+  }
+  const size_t stat = ((size_t)b * p.heads + head) * p.n + (qok ? qrow : 0);
+  const float nlse = qok ? -p.lse[stat] : -INFINITY;     // invalid rows: P = exp2(s + (-inf)) = 0... (see below)
+  const float ndelta = qok ? -p.delta[stat] : 0.f;
+
+  const int srow0 = tid >> 3, sc = tid & 7;
+  const int tiles_own = (p.n + KT - 1) / KT;
+  const int tiles_bank = (p.nshot > 0 && bank_b >= 0) ? tiles_own : 0;
+  const int ntiles = tiles_own + (tiles_bank ? p.nshot * tiles_bank : 0);
+  i32x4 gk[2], gv[2];
+  auto issue = [&](int t) {
+    int img = b, tt = t;
+    if (t >= tiles_own) { img = bank_b * p.nshot + (t - tiles_own) / tiles_bank; tt = (t - tiles_own) % tiles_bank; }
+    const size_t base = (size_t)img * p.bs + head * 64 + sc * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = tt * KT + srow0 + 32 * i;
+      const uint32_t o = key < p.n ? (uint32_t)((base + (size_t)key * p.ld) * sizeof(T)) : kOOB;
+      gk[i] = buf_load16(rqkv, o == kOOB ? kOOB : o + koff);
+      gv[i] = buf_load16(rqkv, o == kOOB ? kOOB : o + voff);
+    }
+  };
+  auto write_lds = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow0 + 32 * i;
+      *(i32x4*)(buf + row_off(row, sc)) = gk[i];
+      *(i32x4*)(buf + TILE + tr_off(row, sc * 8)) = gk[i];
+      *(i32x4*)(buf + 2 * TILE + row_off(row, sc)) = gv[i];
+    }
+  };
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+
+  issue(0);
+  write_lds(smem);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) issue(t + 1);
+    const char* kbuf = smem + cur * 3 * TILE;
+    const char* ktr = kbuf + TILE;
+    const char* vbuf = kbuf + 2 * TILE;
+    int tt = t;
+    if (t >= tiles_own) tt = (t - tiles_own) % tiles_bank;
+    const int nvalid = p.n - tt * KT;
+    // S^T = K Q^T - lse ;  dP^T = V dO^T - delta   (row constants as initial accumulators)
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[kb][r] = qok ? nlse : 0.f; dp[kb][r] = ndelta; }
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const int row = kb * 32 + lr;
+        const typename Tr<T>::v8 kf = as_v8<T>(*(const i32x4*)(kbuf + row_off(row, 2 * ss + lh)));
+        const typename Tr<T>::v8 vf = as_v8<T>(*(const i32x4*)(vbuf + row_off(row, 2 * ss + lh)));
+        s[kb] = Tr<T>::mfma(kf, qf[ss], s[kb]);
+        dp[kb] = Tr<T>::mfma(vf, dof[ss], dp[kb]);
+      }
+    }
+    // dS^T = P^T o dP^T ; rows of S^T are keys: (r & 3) + 8 (r >> 2) + 4 lh within the 32-key block
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float pr = (qok && key < nvalid) ? __builtin_amdgcn_exp2f(s[kb][r]) : 0.f;
+        s[kb][r] = pr * dp[kb][r];
+      }
+    // dQ^T += K^T dS^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        typename Tr<T>::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (T)s[kb][8 * t2 + j];
+        const int row0 = kb * 32 + 16 * t2 + 4 * lh + tq, row1 = row0 + 8;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int dcol = d * 32 + 16 * tg + 4 * tp;
+          const typename Tr<T>::v4 lo = lds_tr_read<T>(ktr + tr_off(row0, dcol));
+          const typename Tr<T>::v4 hi = lds_tr_read<T>(ktr + tr_off(row1, dcol));
+          typename Tr<T>::v8 kf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { kf[j] = lo[j]; kf[4 + j] = hi[j]; }
+          o[d] = Tr<T>::mfma(kf, pf, o[d]);
+        }
+      }
+    if (more) write_lds(smem + (cur ^ 1) * 3 * TILE);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (qok) {
+    char* ob = p.dq + ((size_t)b * p.dbs + (size_t)qrow * p.ldd + head * 64) * sizeof(T);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * p.scale;
+        *(i32x2*)(ob + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(v);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
+  constexpr int QT = 64, TILE = QT * 128;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [Q rows | Q tr | dO rows | dO tr] (32 KiB, single buffer)
+  __shared__ float stats[2][QT];                                  // [-lse | -delta][q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, kimg = blockIdx.z;
+  const int key = blockIdx.x * 128 + wave * 32 + lr;      // the key this lane owns (column of S)
+  const bool kok = key < p.n;
+  const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.dout, p.do_bytes);
+  const uint32_t koff = (uint32_t)((const char*)p.k - (const char*)p.q), voff = (uint32_t)((const char*)p.v - (const char*)p.q);
+  // B operands: lane holds K[key][16 s + 8 lh + 0..7] (= K^T[k = d][col = key]), same for V
+  typename Tr<T>::v8 kf[4], vf[4];
+  {
+    const uint32_t base = kok ? (uint32_t)(((size_t)kimg * p.bs + (size_t)key * p.ld + head * 64 + lh * 8) * sizeof(T)) : kOOB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = as_v8<T>(buf_load16(rqkv, base == kOOB ? kOOB : base + koff + (uint32_t)(s * 32)));
+      vf[s] = as_v8<T>(buf_load16(rqkv, base == kOOB ? kOOB : base + voff + (uint32_t)(s * 32)));
+    }
+  }
+  // query sources: the image's own rows, plus (support image of a lock-step batch) its episode's query image
+  const int nsrc = (p.nshot > 0 && kimg < p.n_plain) ? 2 : 1;
+  const int src1 = p.nshot > 0 ? p.n_plain + kimg / p.nshot : 0;
+  const int tiles_q = (p.n + QT - 1) / QT;
+  const int ntiles = nsrc * tiles_q;
+
+  const int srow0 = tid >> 3, sc = tid & 7;
+  i32x4 gq[2], gd[2];
+  float gst = 0.f;
+  auto issue = [&](int t) {
+    const int img = t < tiles_q ? kimg : src1, tt = t < tiles_q ? t : t - tiles_q;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qi = tt * QT + srow0 + 32 * i;
+      const bool ok = qi < p.n;
+      gq[i] = buf_load16(rqkv, ok ? (uint32_t)(((size_t)img * p.bs + (size_t)qi * p.ld + head * 64 + sc * 8) * sizeof(T)) : kOOB);
+      gd[i] = buf_load16(rdo, ok ? (uint32_t)(((size_t)img * p.obs + (size_t)qi * p.ldo + head * 64 + sc * 8) * sizeof(T)) : kOOB);
+    }
+    if (tid < 2 * QT) {       // threads 0..63: -lse, 64..127: -delta of the tile's rows
+      const int qi = tt * QT + (tid & 63);
+      const size_t st = ((size_t)img * p.heads + head) * p.n + qi;
+      if (qi < p.n) gst = tid < QT ? -p.lse[st] : -p.delta[st];
+      else gst = tid < QT ? -INFINITY : 0.f;        // rows past the end: P = exp2(-inf) = 0
+    }
+  };
+  auto write_lds = [&]() {
+    char* base = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow0 + 32 * i;
+      *(i32x4*)(base + row_off(row, sc)) = gq[i];
+      *(i32x4*)(base + TILE + tr_off(row, sc * 8)) = gq[i];
+      *(i32x4*)(base + 2 * TILE + row_off(row, sc)) = gd[i];
+      *(i32x4*)(base + 3 * TILE + tr_off(row, sc * 8)) = gd[i];
+    }
+    if (tid < 2 * QT) stats[tid >> 6][tid & 63] = gst;
+  };
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  f32x16 dk[2], dv[2];     // dK^T / dV^T [d block][rows d, col = key]
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+  issue(0);
+  write_lds();
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) issue(t + 1);          // next tile's global loads fly during this tile's MFMAs
+    const char* qrow_t = smem;
+    const char* qtr = qrow_t + TILE;
+    const char* drow = qrow_t + 2 * TILE;
+    const char* dtr = qrow_t + 3 * TILE;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      // S = Q K^T - lse ; dP = dO V^T - delta   (rows = queries: (r & 3) + 8 (r >> 2) + 4 lh of the 32-row block)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        s[r] = stats[0][qi];
+        dp[r] = stats[1][qi];
+      }
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const int row = qb * 32 + lr;
+        const typename Tr<T>::v8 qa = as_v8<T>(*(const i32x4*)(qrow_t + row_off(row, 2 * ss + lh)));
+        const typename Tr<T>::v8 da = as_v8<T>(*(const i32x4*)(drow + row_off(row, 2 * ss + lh)));
+        s = Tr<T>::mfma(qa, kf[ss], s);
+        dp = Tr<T>::mfma(da, vf[ss], dp);
+      }
+      typename Tr<T>::v8 pf[2], sf[2];       // P and dS as B operands: k-step t2 <- registers 8 t2 .. 8 t2 + 7
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = kok ? __builtin_amdgcn_exp2f(s[r]) : 0.f;
+        pf[r >> 3][r & 7] = (T)pr;
+        sf[r >> 3][r & 7] = (T)(pr * dp[r]);
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS   (A fragments: transposed reads, rows in the accumulator's k order)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int row0 = qb * 32 + 16 * t2 + 4 * lh + tq, row1 = row0 + 8;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int dcol = d * 32 + 16 * tg + 4 * tp;
+          const typename Tr<T>::v4 dlo = lds_tr_read<T>(dtr + tr_off(row0, dcol)), dhi = lds_tr_read<T>(dtr + tr_off(row1, dcol));
+          const typename Tr<T>::v4 qlo = lds_tr_read<T>(qtr + tr_off(row0, dcol)), qhi = lds_tr_read<T>(qtr + tr_off(row1, dcol));
+          typename Tr<T>::v8 da, qa;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { da[j] = dlo[j]; da[4 + j] = dhi[j]; qa[j] = qlo[j]; qa[4 + j] = qhi[j]; }
+          dv[d] = Tr<T>::mfma(da, pf[t2], dv[d]);
+          dk[d] = Tr<T>::mfma(qa, sf[t2], dk[d]);
+        }
+      }
+    }
+    __syncthreads();                  // every wave is done reading this tile
+    if (more) write_lds();
+    __syncthreads();
+  }
+  if (kok) {
+    // D layout of dK^T / dV^T: col = key (this lane), rows d = (r & 3) + 8 (r >> 2) + 4 lh of the 32-d block
+    char* kb = p.dk + ((size_t)kimg * p.dbs + (size_t)key * p.ldd + head * 64) * sizeof(T);
+    char* vb = p.dv + ((size_t)kimg * p.dbs + (size_t)key * p.ldd + head * 64) * sizeof(T);
+    const float ln2 = 0.6931471805599453f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a[4], c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = dk[d][4 * g + e] * ln2; c[e] = dv[d][4 * g + e]; }
+        *(i32x2*)(kb + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(a);
+        *(i32x2*)(vb + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(c);
+      }
+  }
+}
+
+}  // namespace dfw
+
+using namespace dfw;
+
+extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream) {
+  if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->delta || !a->dqkv) return DFW_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->nshot < 0 || a->n_plain < 0 || a->n_plain > a->batch) return DFW_EINVAL;
+  if (a->nshot > 0 && (a->n_plain <= 0 || (a->batch - a->n_plain) * a->nshot != a->n_plain)) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  const int C = a->heads * 64;
+  if ((a->ld % 8) || (a->ldo % 8) || (a->ldd % 8) || a->ld < 3 * C || a->ldd < 3 * C || a->ldo < C) return DFW_ESHAPE;
+  const int64_t qe = (int64_t)a->batch * a->n * a->ld, oe = (int64_t)a->batch * a->n * a->ldo, de = (int64_t)a->batch * a->n * a->ldd;
+  if (qe >= (1ll << 30) || oe >= (1ll << 30) || de >= (1ll << 30)) return DFW_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = a->dtype == DFW_BF16;
+  const size_t es = 2;
+  // delta = rowsum(dO o O)
+  {
+    const long long total = (long long)a->batch * a->heads * a->n;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
+    else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
+    DFW_CHECK_LAUNCH();
+  }
+  FsaBwdP p;
+  p.q = (const char*)a->qkv; p.k = p.q + (size_t)C * es; p.v = p.q + (size_t)2 * C * es;
+  p.dout = (const char*)a->dout; p.lse = a->lse; p.delta = a->delta;
+  p.dq = (char*)a->dqkv; p.dk = p.dq + (size_t)C * es; p.dv = p.dq + (size_t)2 * C * es;
+  p.qkv_bytes = (uint32_t)(qe * es); p.do_bytes = (uint32_t)(oe * es); p.dqkv_bytes = (uint32_t)(de * es);
+  p.batch = a->batch; p.heads = a->heads; p.n = a->n; p.nshot = a->nshot; p.n_plain = a->n_plain;
+  p.ld = a->ld; p.ldo = a->ldo; p.ldd = a->ldd;
+  p.bs = (long long)a->n * a->ld; p.obs = (long long)a->n * a->ldo; p.dbs = (long long)a->n * a->ldd;
+  p.scale = a->scale;
+  dim3 grid((a->n + 127) / 128, a->heads, a->batch);
+  if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  if (bf) hipLaunchKernelGGL((fsa_bwd_dkv_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fsa_bwd_dkv_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,942 @@
+// Backward kernels of the training step (train_icl_multitask_nocrop_nearest_nshot_v3.py:1374-1396):
+// weight gradients (a TN GEMM on MFMA with both operands read transposed out of row-major LDS tiles), bias /
+// time-projection gradients (column sums), GroupNorm / LayerNorm / GEGLU backward, the small data-movement
+// pieces of the conv backward (zero-stuffing for stride 2, 2x2 pooling for the fused upsample), the loss
+// gradient, and the optimizer step.  Data gradients of Linear / conv3x3 reuse the FORWARD implicit-GEMM kernels
+// with transposed / tap-mirrored weights (dfw_gemm); the attention backward lives in attention_bwd.hip.
+// Deterministic throughout: split reductions go through fp32 slabs folded in a fixed order, no float atomics.
+#include "common.h"
+#include "attention_common.h"
+
+namespace dfw {
+
+// ---------------------------------------------------------------------------------------------
+// TN GEMM:  C[z][n][k] = sum_m A[m][n] * B[row(m, tap)][k]      (fp32 out)
+//   Linear weight gradient:  A = dY [M][N], B = X [M][K]          (dW = dY^T X, torch.nn.Linear.weight layout)
+//   conv3x3 weight gradient: taps = 9, B rows gathered with the forward conv's im2col addressing
+//                            (stride / pad / fused nearest-2x upsample), C[n][tap][k] = packed [Cout][ky][kx][Cin]
+// The reduction index m is the ROW index of both operands, so both MFMA fragments are transposed reads
+// (ds_read_b64_tr_b16) of row-major [64 m][128 cols] LDS tiles; the image is guide image (b) (256-byte rows,
+// 16-byte chunk ch of row r at 16 * (ch ^ (((r & 3) << 2) | ((r >> 2) & 3)))): conflict-free transposed reads.
+// Workgroup = 4 waves = 128 x 128 output tile (wave: 64 x 64 = 2 x 2 MFMA 32x32x16 blocks); M is split over
+// gridDim.y workgroups writing fp32 slabs, folded by tn_reduce_kernel in split order.
+struct TnP {
+  const char* A; const char* B; float* slab;
+  uint32_t a_bytes, b_bytes;
+  int M, N, Kc, lda, ldb;
+  int taps, Hi, Wi, Ho, Wo, stride, pad, ups;
+  int splits, mchunk;
+  int batch2; long long strideA, strideB, strideA2, strideB2;   // z = (b1 * batch2 + b2) * taps + tap
+};
+
+__device__ __forceinline__ uint32_t tn_off(int row, int ch) {
+  return (uint32_t)(256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnP p) {
+  constexpr int TILE = 64 * 256;   // bytes of one [64][128] tile
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [buf][A|B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int lh = lane >> 5;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int ntk = (p.Kc + 127) >> 7;
+  const int n0 = ((int)blockIdx.x / ntk) * 128, k0 = ((int)blockIdx.x % ntk) * 128;
+  const int split = blockIdx.y, z = blockIdx.z;
+  const int tap = z % p.taps, bb = z / p.taps;
+  const int b1 = bb / p.batch2, b2 = bb - b1 * p.batch2;
+  const char* Ab = p.A + ((size_t)b1 * p.strideA + (size_t)b2 * p.strideA2) * sizeof(T);
+  const char* Bb = p.B + ((size_t)b1 * p.strideB + (size_t)b2 * p.strideB2) * sizeof(T);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, p.a_bytes), rb = make_rsrc(Bb, p.b_bytes);
+  const int m_begin = split * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
+  const int nsteps = (m_end - m_begin + 63) >> 6;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const unsigned limH = p.ups ? 2 * p.Hi : p.Hi, limW = p.ups ? 2 * p.Wi : p.Wi;
+  const int ush = p.ups ? 1 : 0;
+
+  i32x4 ga[4], gb[4];
+  auto issue = [&](int step) {
+    const int mb = m_begin + step * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, row = e >> 4, ch = e & 15;
+      const int m = mb + row;
+      const bool okm = m < m_end;
+      const int na = n0 + ch * 8, kb = k0 + ch * 8;
+      ga[i] = buf_load16(ra, (okm && na < p.N) ? (uint32_t)(((size_t)m * p.lda + na) * sizeof(T)) : kOOB);
+      uint32_t off = kOOB;
+      if (okm && kb < p.Kc) {
+        if (p.taps == 1) {
+          off = (uint32_t)(((size_t)m * p.ldb + kb) * sizeof(T));
+        } else {
+          const int hw = p.Ho * p.Wo;
+          const int img = m / hw, rem = m - img * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+          if ((unsigned)iy < limH && (unsigned)ix < limW) {
+            iy >>= ush;
+            ix >>= ush;
+            off = (uint32_t)((((size_t)img * p.Hi + iy) * p.Wi + ix) * p.ldb + kb) * (uint32_t)sizeof(T);
+          }
+        }
+      }
+      gb[i] = buf_load16(rb, off);
+    }
+  };
+  auto write_lds = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, row = e >> 4, ch = e & 15;
+      *(i32x4*)(buf + tn_off(row, ch)) = ga[i];
+      *(i32x4*)(buf + TILE + tn_off(row, ch)) = gb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) {
+    issue(0);
+    write_lds(smem);
+    __syncthreads();
+  }
+  int cur = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) issue(s + 1);
+    const char* at = smem + cur * 2 * TILE;
+    const char* bt = at + TILE;
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      typename Tr<T>::v8 fa[2], fb[2];
+      const int r0 = ss * 16 + 8 * lh + tq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ca = wn * 8 + i * 4 + 2 * tg + (tp >> 1), cb = wk * 8 + i * 4 + 2 * tg + (tp >> 1);
+        const typename Tr<T>::v4 alo = lds_tr_read<T>(at + tn_off(r0, ca) + 8 * (tp & 1));
+        const typename Tr<T>::v4 ahi = lds_tr_read<T>(at + tn_off(r0 + 4, ca) + 8 * (tp & 1));
+        const typename Tr<T>::v4 blo = lds_tr_read<T>(bt + tn_off(r0, cb) + 8 * (tp & 1));
+        const typename Tr<T>::v4 bhi = lds_tr_read<T>(bt + tn_off(r0 + 4, cb) + 8 * (tp & 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fa[i][j] = alo[j]; fa[i][4 + j] = ahi[j]; fb[i][j] = blo[j]; fb[i][4 + j] = bhi[j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Tr<T>::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) write_lds(smem + (cur ^ 1) * 2 * TILE);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // D layout: col = lane & 31 (k), row = (r & 3) + 8 * (r >> 2) + 4 * lh (n)
+  float* out = p.slab + ((size_t)split * gridDim.z + z) * (size_t)p.N * p.Kc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+      if (k >= p.Kc) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < p.N) out[(size_t)n * p.Kc + k] = acc[i][j][r];
+      }
+    }
+}
+
+// out[b * ldo_b + n * ldo_n + tap * ldo_t + k] (+)= scale * sum_s slab[s][z][n][k], z = b * taps + tap
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, float* out, int splits, int Z, int taps, int N,
+                                                        int Kc, long long ldo_b, long long ldo_n, long long ldo_t,
+                                                        float scale, int accumulate) {
+  const long long per = (long long)N * Kc, total = per * Z;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int z = (int)(e / per);
+    const long long r = e - (long long)z * per;
+    const int n = (int)(r / Kc), k = (int)(r - (long long)n * Kc);
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + e];
+    float* o = out + (size_t)(z / taps) * ldo_b + (size_t)n * ldo_n + (size_t)(z % taps) * ldo_t + k;
+    *o = (accumulate ? *o : 0.f) + scale * s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums: part[seg][chunk][n] = sum over the chunk's rows of x[seg * rows_per_seg + row][n]; the fold over
+// chunks (fixed order) writes out[seg][n].  Bias gradients (one segment) and the per-image time-embedding
+// projection gradient (segment = image): d(rowbias)[img][n] = sum_pixels dY.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const char* x, float* part, int rows_per_seg, int N, int ldx, int rpc) {
+  __shared__ float red[8][256];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = ((int)blockIdx.x * 32 + cl) * 8;
+  const int chunk = blockIdx.y, seg = blockIdx.z;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  if (n < N) {
+    const int r1 = min(rows_per_seg, (chunk + 1) * rpc);
+    for (int r = chunk * rpc + rl; r < r1; r += 8) {
+      float f[8];
+      unpack8<T>(*(const i32x4*)(x + (((size_t)seg * rows_per_seg + r) * ldx + n) * sizeof(T)), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cl * 8 + i] = s[i];
+  __syncthreads();
+  const int c = threadIdx.x;   // 256 columns of this block
+  const int nn = (int)blockIdx.x * 256 + c;
+  if (nn < N) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a += red[r][c];
+    part[((size_t)seg * gridDim.y + chunk) * N + nn] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* part, float* out, int chunks, int N, int segs,
+                                                          long long ldo, float scale, int accumulate) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)segs * N) return;
+  const int seg = (int)(e / N), n = (int)(e - (long long)seg * N);
+  float a = 0.f;
+  for (int c = 0; c < chunks; ++c) a += part[((size_t)seg * chunks + c) * N + n];
+  float* o = out + (size_t)seg * ldo + n;
+  *o = (accumulate ? *o : 0.f) + scale * a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) backward on NHWC.  y = act(gamma * xhat + beta), xhat = (x - mean_g) * rstd_g.
+//   dz = dy * act'(z)                      dgamma[c] = sum dz * xhat      dbeta[c] = sum dz
+//   dx = rstd * (gamma * dz - mean_g(gamma * dz) - xhat * mean_g(gamma * dz * xhat))
+// Pass 1: per (image, pixel chunk) per-channel (sum dz, sum dz * xhat); pass 2: fold chunks, parameter
+// gradients and the two group means; pass 3: dx.  Thread = 8 fixed channels, like the forward kernels.
+struct GnbP {
+  const char* x; const char* dy; char* dx; const float* gamma; const float* beta; const float* mr;
+  float* part;   // [B][chunks][C][2]
+  float* gs;     // [B][groups][2]  (mean_g(gamma dz), mean_g(gamma dz xhat))
+  float* dgamma; float* dbeta;
+  int B, HW, C, groups, ldx, lddy, lddx, chunks, ppc, silu, accumulate;
+  float gscale;   // parameter gradients are scaled by this (1 / loss scale)
+};
+
+__device__ __forceinline__ float silu_grad(float z) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+
+template <typename T>
+__global__ void gn_bwd_stats_kernel(const GnbP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  float* ls = (float*)smem_b;   // [slots][C][2]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cpg = p.C / p.groups, tpp = p.C >> 3, slots = blockDim.x / tpp;
+  const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  const int p0 = chunk * p.ppc, p1 = min(p.HW, p0 + p.ppc);
+  float mean[8], rstd[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cc * 8 + i, g = c / cpg;
+    mean[i] = p.mr[(b * p.groups + g) * 2];
+    rstd[i] = p.mr[(b * p.groups + g) * 2 + 1];
+    ga[i] = p.gamma ? p.gamma[c] : 1.f;
+    be[i] = p.beta ? p.beta[c] : 0.f;
+    s1[i] = 0.f;
+    s2[i] = 0.f;
+  }
+  for (int px = p0 + slot; px < p1; px += slots) {
+    float fx[8], fd[8];
+    unpack8<T>(*(const i32x4*)(p.x + (((size_t)b * p.HW + px) * p.ldx + cc * 8) * sizeof(T)), fx);
+    unpack8<T>(*(const i32x4*)(p.dy + (((size_t)b * p.HW + px) * p.lddy + cc * 8) * sizeof(T)), fd);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (fx[i] - mean[i]) * rstd[i];
+      const float dz = p.silu ? fd[i] * silu_grad(ga[i] * xh + be[i]) : fd[i];
+      s1[i] += dz;
+      s2[i] += dz * xh;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ls[((size_t)slot * p.C + cc * 8 + i) * 2 + 0] = s1[i];
+    ls[((size_t)slot * p.C + cc * 8 + i) * 2 + 1] = s2[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float a = 0.f, a2 = 0.f;
+    for (int sl = 0; sl < slots; ++sl) {
+      a += ls[((size_t)sl * p.C + c) * 2 + 0];
+      a2 += ls[((size_t)sl * p.C + c) * 2 + 1];
+    }
+    float* o = p.part + (((size_t)b * p.chunks + chunk) * p.C + c) * 2;
+    o[0] = a;
+    o[1] = a2;
+  }
+}
+
+// one thread per channel: fold chunks per image (kept in part[b][0][c]), then parameter gradients over images
+__global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const GnbP p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  float dg = 0.f, db = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    float a = 0.f, a2 = 0.f;
+    for (int ch = 0; ch < p.chunks; ++ch) {
+      const float* o = p.part + (((size_t)b * p.chunks + ch) * p.C + c) * 2;
+      a += o[0];
+      a2 += o[1];
+    }
+    float* o0 = p.part + (((size_t)b * p.chunks) * p.C + c) * 2;
+    o0[0] = a;
+    o0[1] = a2;
+    db += a;
+    dg += a2;
+  }
+  if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * dg;
+  if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * db;
+}
+
+__global__ __launch_bounds__(64) void gn_bwd_group_kernel(const GnbP p) {
+  const int bg = blockIdx.x, b = bg / p.groups, g = bg - b * p.groups;
+  const int cpg = p.C / p.groups;
+  float a = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < cpg; i += 64) {
+    const int c = g * cpg + i;
+    const float w = p.gamma ? p.gamma[c] : 1.f;
+    const float* o = p.part + (((size_t)b * p.chunks) * p.C + c) * 2;
+    a += w * o[0];
+    a2 += w * o[1];
+  }
+  a = wave_sum(a);
+  a2 = wave_sum(a2);
+  if (threadIdx.x == 0) {
+    const float n = (float)p.HW * cpg;
+    p.gs[bg * 2 + 0] = a / n;
+    p.gs[bg * 2 + 1] = a2 / n;
+  }
+}
+
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const GnbP p) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cpg = p.C / p.groups, tpp = p.C >> 3, slots = blockDim.x / tpp;
+  const int cc = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+  const int p0 = chunk * p.ppc, p1 = min(p.HW, p0 + p.ppc);
+  float mean[8], rstd[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cc * 8 + i, g = c / cpg;
+    mean[i] = p.mr[(b * p.groups + g) * 2];
+    rstd[i] = p.mr[(b * p.groups + g) * 2 + 1];
+    ga[i] = p.gamma ? p.gamma[c] : 1.f;
+    be[i] = p.beta ? p.beta[c] : 0.f;
+    m1[i] = p.gs[(b * p.groups + g) * 2];
+    m2[i] = p.gs[(b * p.groups + g) * 2 + 1];
+  }
+  for (int px = p0 + slot; px < p1; px += slots) {
+    float fx[8], fd[8], o[8];
+    unpack8<T>(*(const i32x4*)(p.x + (((size_t)b * p.HW + px) * p.ldx + cc * 8) * sizeof(T)), fx);
+    unpack8<T>(*(const i32x4*)(p.dy + (((size_t)b * p.HW + px) * p.lddy + cc * 8) * sizeof(T)), fd);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (fx[i] - mean[i]) * rstd[i];
+      const float dz = p.silu ? fd[i] * silu_grad(ga[i] * xh + be[i]) : fd[i];
+      o[i] = rstd[i] * (ga[i] * dz - m1[i] - xh * m2[i]);
+    }
+    *(i32x4*)(p.dx + (((size_t)b * p.HW + px) * p.lddx + cc * 8) * sizeof(T)) = pack8<T>(o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row (row, dy and the statistics in registers), rows strided over the grid;
+// each wave keeps per-channel partial (dgamma, dbeta) for its rows, folded per block then by ln_bwd_fold_kernel.
+struct LnbP {
+  const char* x; const char* dy; char* dx; const float* gamma; float* part; float* dgamma; float* dbeta;
+  int rows, C, ldx, lddy, lddx, nblocks, accumulate;
+  float eps, gscale;
+};
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnbP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_l[];
+  float* red = (float*)smem_l;   // [4 waves][C][2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = p.C >> 3;
+  float pg[MAXC][8], pb[MAXC][8], gm[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pg[i][j] = 0.f;
+      pb[i][j] = 0.f;
+      gm[i][j] = ch < nch ? p.gamma[ch * 8 + j] : 0.f;
+    }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+    float f[MAXC][8], d[MAXC][8];
+    const char* xr = p.x + (size_t)row * p.ldx * sizeof(T);
+    const char* dr = p.dy + (size_t)row * p.lddy * sizeof(T);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        unpack8<T>(*(const i32x4*)(xr + ch * 16), f[i]);
+        unpack8<T>(*(const i32x4*)(dr + ch * 16), d[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[i][j];
+      }
+    }
+    const float mean = wave_sum(s) / p.C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = f[i][j] - mean; v += t * t; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (f[i][j] - mean) * rstd;
+          f[i][j] = xh;
+          pb[i][j] += d[i][j];
+          pg[i][j] += d[i][j] * xh;
+          const float gd = gm[i][j] * d[i][j];
+          d[i][j] = gd;
+          a1 += gd;
+          a2 += gd * xh;
+        }
+      }
+    }
+    const float m1 = wave_sum(a1) / p.C, m2 = wave_sum(a2) / p.C;
+    char* orow = p.dx + (size_t)row * p.lddx * sizeof(T);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (d[i][j] - m1 - f[i][j] * m2);
+        *(i32x4*)(orow + ch * 16) = pack8<T>(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[((size_t)wave * p.C + ch * 8 + j) * 2 + 0] = pg[i][j];
+        red[((size_t)wave * p.C + ch * 8 + j) * 2 + 1] = pb[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[((size_t)w * p.C + c) * 2 + 0];
+      b += red[((size_t)w * p.C + c) * 2 + 1];
+    }
+    p.part[((size_t)blockIdx.x * p.C + c) * 2 + 0] = a;
+    p.part[((size_t)blockIdx.x * p.C + c) * 2 + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const LnbP p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < p.nblocks; ++k) {
+    a += p.part[((size_t)k * p.C + c) * 2 + 0];
+    b += p.part[((size_t)k * p.C + c) * 2 + 1];
+  }
+  p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * a;
+  p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEGLU (diffusers GEGLU.forward: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)) on the PACKED column
+// order of packing.pack_geglu: 64-column groups of 32 value columns followed by their 32 gate columns.
+__device__ __forceinline__ float gelu_grad(float g) {
+  const float cdf = 0.5f * (1.0f + erf_as(g * 0.70710678118654752f));
+  return cdf + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const char* pre, char* out, long long rows, int H) {
+  // thread = 8 output columns (one 16-byte piece of a 32-column value block)
+  const long long per = H >> 3, total = rows * per;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long m = e / per;
+    const int oc = (int)(e - m * per) * 8, grp = oc >> 5, j = oc & 31;
+    float a[8], g[8], o[8];
+    unpack8<T>(*(const i32x4*)(pre + ((size_t)m * 2 * H + grp * 64 + j) * sizeof(T)), a);
+    unpack8<T>(*(const i32x4*)(pre + ((size_t)m * 2 * H + grp * 64 + 32 + j) * sizeof(T)), g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = a[i] * gelu_erf(g[i]);
+    *(i32x4*)(out + ((size_t)m * H + oc) * sizeof(T)) = pack8<T>(o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const char* pre, const char* dout, char* dpre, long long rows, int H) {
+  const long long per = H >> 3, total = rows * per;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long m = e / per;
+    const int oc = (int)(e - m * per) * 8, grp = oc >> 5, j = oc & 31;
+    float a[8], g[8], d[8], da[8], dg[8];
+    unpack8<T>(*(const i32x4*)(pre + ((size_t)m * 2 * H + grp * 64 + j) * sizeof(T)), a);
+    unpack8<T>(*(const i32x4*)(pre + ((size_t)m * 2 * H + grp * 64 + 32 + j) * sizeof(T)), g);
+    unpack8<T>(*(const i32x4*)(dout + ((size_t)m * H + oc) * sizeof(T)), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      da[i] = d[i] * gelu_erf(g[i]);
+      dg[i] = d[i] * a[i] * gelu_grad(g[i]);
+    }
+    *(i32x4*)(dpre + ((size_t)m * 2 * H + grp * 64 + j) * sizeof(T)) = pack8<T>(da);
+    *(i32x4*)(dpre + ((size_t)m * 2 * H + grp * 64 + 32 + j) * sizeof(T)) = pack8<T>(dg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise data movement of the backward graph (all on 16-byte pieces).
+//   mode 0: y = a + b                       (gradient of a tensor used twice: residual / skip connections)
+//   mode 1: y = a[:, c0 : c0 + C]           (backward of torch.cat([h, skip], dim=1), U:1226: a has ld columns)
+//   mode 2: zero-stuff  y[b][2y][2x] = a[b][y][x], 0 elsewhere     (data gradient of a stride-2 conv = stride-1
+//           conv of the zero-stuffed output gradient with mirrored taps)
+//   mode 3: y[b][y][x] = sum of the 2x2 block of a[b][2y..][2x..]  (backward of the nearest-2x upsample fused
+//           into Upsample2D's conv)
+template <typename T>
+__global__ __launch_bounds__(256) void ew_kernel(const char* a, const char* b, char* y, long long rows, int C, int lda,
+                                                 int c0, int H, int W, int mode) {
+  const int per = C >> 3;
+  const long long total = rows * per;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / per;
+    const int c = (int)(e - r * per) * 8;
+    if (mode == 0) {
+      float fa[8], fb[8];
+      unpack8<T>(*(const i32x4*)(a + ((size_t)r * C + c) * sizeof(T)), fa);
+      unpack8<T>(*(const i32x4*)(b + ((size_t)r * C + c) * sizeof(T)), fb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] += fb[i];
+      *(i32x4*)(y + ((size_t)r * C + c) * sizeof(T)) = pack8<T>(fa);
+    } else if (mode == 1) {
+      *(i32x4*)(y + ((size_t)r * C + c) * sizeof(T)) = *(const i32x4*)(a + ((size_t)r * lda + c0 + c) * sizeof(T));
+    } else if (mode == 2) {     // rows = B * 2H * 2W output pixels; H, W = input size
+      const long long hw2 = 4LL * H * W;
+      const long long img = r / hw2;
+      const int rem = (int)(r - img * hw2), oy = rem / (2 * W), ox = rem - oy * 2 * W;
+      i32x4 v = {0, 0, 0, 0};
+      if (((oy | ox) & 1) == 0) v = *(const i32x4*)(a + ((((size_t)img * H + (oy >> 1)) * W + (ox >> 1)) * C + c) * sizeof(T));
+      *(i32x4*)(y + ((size_t)r * C + c) * sizeof(T)) = v;
+    } else {                    // rows = B * H * W output pixels; input is 2H x 2W
+      const long long hw = (long long)H * W;
+      const long long img = r / hw;
+      const int rem = (int)(r - img * hw), oy = rem / W, ox = rem - oy * W;
+      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float f[8];
+          unpack8<T>(*(const i32x4*)(a + ((((size_t)img * 2 * H + 2 * oy + dy) * 2 * W + 2 * ox + dx) * C + c) * sizeof(T)), f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s[i] += f[i];
+        }
+      *(i32x4*)(y + ((size_t)r * C + c) * sizeof(T)) = pack8<T>(s);
+    }
+  }
+}
+
+// NCHW fp32 [B][C][H][W] -> NHWC storage dtype [B][H][W][Cp] (Cp >= C, zero padded), times `scale`
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int HW, int Cp, float scale) {
+  const long long total = (long long)B * HW * Cp;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % Cp);
+    const long long pix = e / Cp;
+    const long long b = pix / HW;
+    const int p = (int)(pix - b * HW);
+    y[e] = c < C ? (T)(x[((size_t)b * C + c) * HW + p] * scale) : (T)0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss: mean((pred - target)^2) over all elements (F.mse_loss(reduction='mean'), T:1384) and its gradient
+// dpred = 2 (pred - target) / numel * loss_scale, written as NHWC storage dtype [B][H][W][8] (channels padded to
+// 8) for the conv_out backward.  Two-level deterministic reduction of the loss value.
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, T* dpred, float* part, int B,
+                                                  int C, int HW, float gscale) {
+  __shared__ float red[4];
+  const long long total = (long long)B * C * HW;
+  float acc = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const float d = pred[e] - target[e];
+    acc += d * d;
+    const long long bc = e / HW;
+    const int p = (int)(e - bc * HW);
+    const long long b = bc / C;
+    const int c = (int)(bc - b * C);
+    dpred[((size_t)b * HW + p) * 8 + c] = (T)(d * gscale);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void fold_scalar_kernel(const float* part, float* out, int n, float scale) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) a += part[i];   // lane-strided, then a fixed butterfly
+  a = wave_sum(a);
+  if (threadIdx.x == 0) *out = a * scale;
+}
+
+// sum of squares of an fp32 vector (gradient norm for clip_grad_norm_, T:1393): partials per block
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* part, long long n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) acc += x[e] * x[e];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// AdamW (torch.optim.AdamW, T:1186-1194: decoupled weight decay) on flat fp32 master parameters, with the
+// clip_grad_norm_ factor (T:1393) read from device memory: g *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)).
+struct AdamP {
+  float* p; const float* g; float* m; float* v; const float* sumsq;
+  long long n;
+  float lr, beta1, beta2, eps, wd, bc1, bc2, max_norm;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamP a) {
+  float clip = 1.f;
+  if (a.sumsq && a.max_norm > 0.f) {
+    const float c = a.max_norm / (sqrtf(*a.sumsq) + 1e-6f);
+    clip = c < 1.f ? c : 1.f;
+  }
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (long long)gridDim.x * 256) {
+    const float g = a.g[e] * clip;
+    float w = a.p[e] * (1.f - a.lr * a.wd);
+    const float m = a.beta1 * a.m[e] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[e] + (1.f - a.beta2) * g * g;
+    a.m[e] = m;
+    a.v[e] = v;
+    const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
+    w -= (a.lr / a.bc1) * (m / denom);
+    a.p[e] = w;
+  }
+}
+
+}  // namespace dfw
+
+using namespace dfw;
+
+static int grid_for(long long items, int cap = 4096) {
+  long long b = (items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+static int tn_plan(const dfw_gemm_tn_args* a, int& splits, int& mchunk, int& Z) {
+  if (!a || !a->A || !a->B || !a->out) return DFW_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->Kc <= 0) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  if ((a->N % 8) || (a->Kc % 8) || (a->lda % 8) || (a->ldb % 8)) return DFW_ESHAPE;
+  if (a->taps != 1 && a->taps != 9) return DFW_ESHAPE;
+  if (a->taps == 9) {
+    if (a->Hi <= 0 || a->Wi <= 0 || a->Ho <= 0 || a->Wo <= 0 || a->stride <= 0) return DFW_EINVAL;
+    if (a->M % (a->Ho * a->Wo)) return DFW_ESHAPE;
+  }
+  if (a->a_elems <= 0 || a->b_elems <= 0 || a->a_elems >= (1ll << 30) || a->b_elems >= (1ll << 30)) return DFW_ERANGE;
+  const int b1 = a->batch > 1 ? a->batch : 1, b2 = a->batch2 > 1 ? a->batch2 : 1;
+  Z = b1 * b2 * a->taps;
+  const long long tiles = (long long)((a->N + 127) / 128) * ((a->Kc + 127) / 128) * Z;
+  const int steps = (a->M + 63) / 64;
+  long long want = (1024 + tiles - 1) / tiles;       // ~4 workgroups per CU in flight
+  if (want > steps) want = steps;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  const int spp = (int)((steps + want - 1) / want);  // 64-row steps per split
+  mchunk = spp * 64;
+  splits = (a->M + mchunk - 1) / mchunk;
+  return 0;
+}
+
+extern "C" size_t dfw_gemm_tn_workspace_bytes(const dfw_gemm_tn_args* a) {
+  int splits, mchunk, Z;
+  if (tn_plan(a, splits, mchunk, Z)) return 0;
+  return (size_t)splits * Z * a->N * a->Kc * sizeof(float);
+}
+
+extern "C" int dfw_gemm_tn(const dfw_gemm_tn_args* a, dfw_stream_t stream) {
+  int splits, mchunk, Z;
+  int rc = tn_plan(a, splits, mchunk, Z);
+  if (rc) return rc;
+  if (!a->workspace || a->workspace_bytes < (size_t)splits * Z * a->N * a->Kc * sizeof(float)) return DFW_EWORKSPACE;
+  TnP p;
+  p.A = (const char*)a->A; p.B = (const char*)a->B; p.slab = (float*)a->workspace;
+  p.a_bytes = (uint32_t)(a->a_elems * 2); p.b_bytes = (uint32_t)(a->b_elems * 2);
+  p.M = a->M; p.N = a->N; p.Kc = a->Kc; p.lda = a->lda; p.ldb = a->ldb;
+  p.taps = a->taps; p.Hi = a->Hi; p.Wi = a->Wi; p.Ho = a->Ho; p.Wo = a->Wo;
+  p.stride = a->stride; p.pad = a->pad; p.ups = a->ups;
+  p.splits = splits; p.mchunk = mchunk;
+  p.batch2 = a->batch2 > 1 ? a->batch2 : 1;
+  p.strideA = a->strideA; p.strideB = a->strideB; p.strideA2 = a->strideA2; p.strideB2 = a->strideB2;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(((a->N + 127) / 128) * ((a->Kc + 127) / 128), splits, Z);
+  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  const long long total = (long long)Z * a->N * a->Kc;
+  const long long ldo_n = a->ldo_n > 0 ? a->ldo_n : (long long)a->taps * a->Kc;
+  const long long ldo_t = a->ldo_t > 0 ? a->ldo_t : a->Kc;
+  const long long ldo_b = a->ldo_b > 0 ? a->ldo_b : (long long)a->N * a->taps * a->Kc;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, st, (const float*)p.slab, a->out, splits, Z,
+                     a->taps, a->N, a->Kc, ldo_b, ldo_n, ldo_t, a->scale, a->accumulate);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+static void colsum_plan(int rows_per_seg, int& chunks, int& rpc) {
+  chunks = (rows_per_seg + 2047) / 2048;
+  if (chunks > 256) chunks = 256;
+  if (chunks < 1) chunks = 1;
+  rpc = (rows_per_seg + chunks - 1) / chunks;
+  rpc = (rpc + 7) & ~7;
+  chunks = (rows_per_seg + rpc - 1) / rpc;
+}
+
+extern "C" size_t dfw_colsum_workspace_bytes(int64_t rows_per_seg, int32_t segs, int32_t N) {
+  if (rows_per_seg <= 0 || segs <= 0 || N <= 0) return 0;
+  int chunks, rpc;
+  colsum_plan((int)rows_per_seg, chunks, rpc);
+  return (size_t)segs * chunks * N * sizeof(float);
+}
+
+extern "C" int dfw_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t rows_per_seg,
+                          int32_t segs, int32_t N, int32_t ldx, int64_t ldo, float scale, int32_t accumulate,
+                          int32_t dtype, dfw_stream_t stream) {
+  if (!x || !out || !workspace || rows_per_seg <= 0 || segs <= 0 || N <= 0) return DFW_EINVAL;
+  if ((N % 8) || (ldx % 8)) return DFW_ESHAPE;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  int chunks, rpc;
+  colsum_plan((int)rows_per_seg, chunks, rpc);
+  if (workspace_bytes < (size_t)segs * chunks * N * sizeof(float)) return DFW_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((N + 255) / 256, chunks, segs);
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, dim3(256), 0, st, (const char*)x, (float*)workspace, (int)rows_per_seg, N, ldx, rpc);
+  else hipLaunchKernelGGL((colsum_kernel<_Float16>), grid, dim3(256), 0, st, (const char*)x, (float*)workspace, (int)rows_per_seg, N, ldx, rpc);
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3(grid_for((long long)segs * N)), dim3(256), 0, st, (const float*)workspace, out,
+                     chunks, N, segs, (long long)(ldo > 0 ? ldo : N), scale, accumulate);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+static int gnb_geometry(const dfw_groupnorm_bwd_args* a, int& chunks, int& ppc, int& threads, int& slots) {
+  if (!a || a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->groups <= 0) return DFW_EINVAL;
+  if (a->C % 8 || a->C % a->groups || a->ldx % 8 || a->lddy % 8 || a->lddx % 8) return DFW_ESHAPE;
+  const int tpp = a->C / 8;
+  if (tpp > 1024) return DFW_ESHAPE;
+  slots = 256 / tpp;
+  if (slots < 1) slots = 1;
+  threads = tpp * slots;
+  int want = 1024 / a->B;
+  if (want < 1) want = 1;
+  ppc = (a->HW + want - 1) / want;
+  if (ppc < slots * 4) ppc = slots * 4;
+  chunks = (a->HW + ppc - 1) / ppc;
+  return 0;
+}
+
+extern "C" size_t dfw_groupnorm_bwd_workspace_bytes(const dfw_groupnorm_bwd_args* a) {
+  int chunks, ppc, threads, slots;
+  if (gnb_geometry(a, chunks, ppc, threads, slots)) return 0;
+  return ((size_t)a->B * chunks * a->C * 2 + (size_t)a->B * a->groups * 2) * sizeof(float);
+}
+
+extern "C" int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t stream) {
+  int chunks, ppc, threads, slots;
+  int rc = gnb_geometry(a, chunks, ppc, threads, slots);
+  if (rc) return rc;
+  if (!a->x || !a->dy || !a->dx || !a->mean_rstd || !a->workspace) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  if (a->workspace_bytes < dfw_groupnorm_bwd_workspace_bytes(a)) return DFW_EWORKSPACE;
+  const size_t lds = (size_t)slots * a->C * 2 * sizeof(float);
+  if (lds > 64 * 1024) return DFW_ESHAPE;
+  GnbP p;
+  p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.dx = (char*)a->dx;
+  p.gamma = a->gamma; p.beta = a->beta; p.mr = a->mean_rstd;
+  p.part = (float*)a->workspace;
+  p.gs = p.part + (size_t)a->B * chunks * a->C * 2;
+  p.dgamma = a->dgamma; p.dbeta = a->dbeta;
+  p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.lddy = a->lddy; p.lddx = a->lddx;
+  p.chunks = chunks; p.ppc = ppc; p.silu = a->silu; p.accumulate = a->accumulate; p.gscale = a->grad_scale;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(chunks, a->B);
+  const bool bf = a->dtype == DFW_BF16;
+  if (bf) hipLaunchKernelGGL((gn_bwd_stats_kernel<__bf16>), grid, dim3(threads), lds, st, p);
+  else hipLaunchKernelGGL((gn_bwd_stats_kernel<_Float16>), grid, dim3(threads), lds, st, p);
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(a->B * a->groups), dim3(64), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  if (bf) hipLaunchKernelGGL((gn_bwd_apply_kernel<__bf16>), grid, dim3(threads), 0, st, p);
+  else hipLaunchKernelGGL((gn_bwd_apply_kernel<_Float16>), grid, dim3(threads), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+static int lnb_blocks(int rows) {
+  int b = (rows + 3) / 4;
+  return b > 512 ? 512 : (b < 1 ? 1 : b);
+}
+
+extern "C" size_t dfw_layernorm_bwd_workspace_bytes(int32_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)lnb_blocks(rows) * C * 2 * sizeof(float);
+}
+
+extern "C" int dfw_layernorm_bwd(const dfw_layernorm_bwd_args* a, dfw_stream_t stream) {
+  if (!a || !a->x || !a->dy || !a->dx || !a->gamma || !a->dgamma || !a->dbeta || !a->workspace) return DFW_EINVAL;
+  if (a->rows <= 0 || a->C <= 0) return DFW_EINVAL;
+  if (a->C % 8 || a->ldx % 8 || a->lddy % 8 || a->lddx % 8 || a->C > 8 * 64 * 4) return DFW_ESHAPE;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  const int nb = lnb_blocks(a->rows);
+  if (a->workspace_bytes < (size_t)nb * a->C * 2 * sizeof(float)) return DFW_EWORKSPACE;
+  LnbP p;
+  p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.dx = (char*)a->dx; p.gamma = a->gamma;
+  p.part = (float*)a->workspace; p.dgamma = a->dgamma; p.dbeta = a->dbeta;
+  p.rows = a->rows; p.C = a->C; p.ldx = a->ldx; p.lddy = a->lddy; p.lddx = a->lddx; p.nblocks = nb;
+  p.accumulate = a->accumulate; p.eps = a->eps; p.gscale = a->grad_scale;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * a->C * 2 * sizeof(float);
+  const int nch = a->C / 8;
+  const bool bf = a->dtype == DFW_BF16;
+  if (nch <= 64) {
+    if (bf) hipLaunchKernelGGL((ln_bwd_kernel<__bf16, 1>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((ln_bwd_kernel<_Float16, 1>), dim3(nb), dim3(256), lds, st, p);
+  } else if (nch <= 128) {
+    if (bf) hipLaunchKernelGGL((ln_bwd_kernel<__bf16, 2>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((ln_bwd_kernel<_Float16, 2>), dim3(nb), dim3(256), lds, st, p);
+  } else {
+    if (bf) hipLaunchKernelGGL((ln_bwd_kernel<__bf16, 4>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((ln_bwd_kernel<_Float16, 4>), dim3(nb), dim3(256), lds, st, p);
+  }
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_geglu(const void* pre, const void* dout, void* out, int64_t rows, int32_t H, int32_t dtype,
+                         dfw_stream_t stream) {
+  if (!pre || !out || rows <= 0 || H <= 0) return DFW_EINVAL;
+  if (H % 32) return DFW_ESHAPE;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for(rows * (H / 8));
+  const bool bf = dtype == DFW_BF16;
+  if (!dout) {
+    if (bf) hipLaunchKernelGGL((geglu_fwd_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)pre, (char*)out, (long long)rows, H);
+    else hipLaunchKernelGGL((geglu_fwd_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)pre, (char*)out, (long long)rows, H);
+  } else {
+    if (bf) hipLaunchKernelGGL((geglu_bwd_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)pre, (const char*)dout, (char*)out, (long long)rows, H);
+    else hipLaunchKernelGGL((geglu_bwd_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)pre, (const char*)dout, (char*)out, (long long)rows, H);
+  }
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_elementwise(int32_t mode, const void* a, const void* b, void* y, int64_t rows, int32_t C, int32_t lda,
+                               int32_t c0, int32_t H, int32_t W, int32_t dtype, dfw_stream_t stream) {
+  if (!a || !y || rows <= 0 || C <= 0 || mode < 0 || mode > 3) return DFW_EINVAL;
+  if (mode == 0 && !b) return DFW_EINVAL;
+  if ((C % 8) || (mode == 1 && ((lda % 8) || (c0 % 8) || c0 + C > lda))) return DFW_ESHAPE;
+  if ((mode == 2 || mode == 3) && (H <= 0 || W <= 0)) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for(rows * (C / 8));
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((ew_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a, (const char*)b, (char*)y, (long long)rows, C, lda, c0, H, W, mode);
+  else hipLaunchKernelGGL((ew_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a, (const char*)b, (char*)y, (long long)rows, C, lda, c0, H, W, mode);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t HW, int32_t Cp, float scale,
+                                int32_t dtype, dfw_stream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || Cp < C) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for((long long)B * HW * Cp);
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16>), dim3(g), dim3(256), 0, st, x, (__bf16*)y, B, C, HW, Cp, scale);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16>), dim3(g), dim3(256), 0, st, x, (_Float16*)y, B, C, HW, Cp, scale);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* loss, float* workspace,
+                            int32_t B, int32_t C, int32_t HW, float loss_scale, int32_t dtype, dfw_stream_t stream) {
+  if (!pred || !target || !dpred || !loss || !workspace || B <= 0 || C <= 0 || C > 8 || HW <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)B * C * HW;
+  const int nb = 256;   // workspace: 256 floats
+  const float gscale = 2.0f / (float)total * loss_scale;
+  // channels C..7 of dpred are never written by the kernel: the caller passes a zero-initialised buffer
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((mse_kernel<__bf16>), dim3(nb), dim3(256), 0, st, pred, target, (__bf16*)dpred, workspace, B, C, HW, gscale);
+  else hipLaunchKernelGGL((mse_kernel<_Float16>), dim3(nb), dim3(256), 0, st, pred, target, (_Float16*)dpred, workspace, B, C, HW, gscale);
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fold_scalar_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, loss, nb, 1.0f / (float)total);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_sumsq(const float* x, float* out, float* workspace, int64_t n, dfw_stream_t stream) {
+  if (!x || !out || !workspace || n <= 0) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = 1024;    // workspace: 1024 floats
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, x, workspace, (long long)n);
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fold_scalar_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, out, nb, 1.0f);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream) {
+  if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || a->n <= 0 || a->step <= 0) return DFW_EINVAL;
+  AdamP p;
+  p.p = a->param; p.g = a->grad; p.m = a->exp_avg; p.v = a->exp_avg_sq; p.sumsq = a->grad_sumsq;
+  p.n = a->n; p.lr = a->lr; p.beta1 = a->beta1; p.beta2 = a->beta2; p.eps = a->eps; p.wd = a->weight_decay;
+  p.bc1 = 1.0f - powf(a->beta1, (float)a->step);
+  p.bc2 = 1.0f - powf(a->beta2, (float)a->step);
+  p.max_norm = a->max_grad_norm;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n, 8192)), dim3(256), 0, (hipStream_t)stream, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}

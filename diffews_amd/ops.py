@@ -209,7 +209,7 @@ def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
 
 
 def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None, n_plain=0,
-                  q_prescaled=False):
+                  q_prescaled=False, lse=None):
     """KV-fusion self-attention.  q/k/v: [B, N, heads*64] views (token stride = stride(1));
     k_bank/v_bank: [(B-n_plain)*nshot, Nb, heads*64] views written by the support pass.
     n_plain: the first n_plain batch entries ignore the bank (lock-step [support ; query] launch).
@@ -232,6 +232,9 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
         a.ldkb, a.ldvb, a.kb_bs, a.vb_bs = k_bank.stride(1), v_bank.stride(1), k_bank.stride(0), v_bank.stride(0)
     a.scale = scale if scale is not None else 64 ** -0.5
     a.dtype, a.n_plain, a.q_prescaled = _dt(q), n_plain, int(bool(q_prescaled))
+    if lse is not None:   # training: per-row log2-sum-exp2 for the backward
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (B, heads, N)
+        a.lse = lse.data_ptr()
     if gemm_hook is not None:   # bench.py roofline leg: QK^T + PV flops of this launch
         keys = n_plain * k.shape[1] + (B - n_plain) * (k.shape[1] + (nshot * k_bank.shape[1] if nshot else 0))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -269,8 +272,9 @@ def groupnorm_coeff(x, gamma, beta, groups, eps):
     return groupnorm(x, gamma, beta, groups, eps, _coef_only=True)
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False):
-    """GroupNorm (+SiLU) over NHWC x [B, H, W, C] (or [B, HW, C])."""
+def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_stats=False):
+    """GroupNorm (+SiLU) over NHWC x [B, H, W, C] (or [B, HW, C]).
+    return_stats: also return the (mean, rstd) [B, groups, 2] fp32 the kernel normalised with (training)."""
     assert x.is_contiguous()
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
@@ -294,6 +298,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False):
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     a.stats_ws, a.stats_ws_bytes = ws.data_ptr(), nbytes
     L.check(lib.dfw_groupnorm(C.byref(a), _stream()), "dfw_groupnorm")
+    if return_stats:
+        return y, ws[ws.numel() - B * groups * 2:].view(B, groups, 2)
     return y
 
 

@@ -1,0 +1,225 @@
+"""Host-side wrappers of the backward kernels (include/diffews_hip.h, "Training step").
+
+Counterpart of ops.py for the training step of
+/root/reference/train_tools/train_icl_multitask_nocrop_nearest_nshot_v3.py:1374-1396: torch tensors carry device
+memory and the current stream only; every gradient is computed by libdiffews_hip.so.  Activation gradients are
+NHWC / [rows, C] tensors in the engine storage dtype, parameter gradients fp32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .ops import _dt, _p, _stream, _f32
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=device)
+
+
+def gemm_tn(dy, x, n=None, kc=None, out=None, taps=1, geom=None, accumulate=False, scale=1.0, batch=1, batch2=1,
+            strides=(0, 0, 0, 0), M=None, lda=None, ldb=None, out_strides=(0, 0, 0)):
+    """out[b][n][tap][k] (+)= scale * sum_m dy[m][n] * x[row(m, tap)][k]   (fp32).
+    dy [M, >=n] / x [rows, >=kc] are 2-D (or NHWC) storage-dtype tensors whose last dim is contiguous.
+    geom = (Hi, Wi, Ho, Wo, stride, pad, ups) for taps == 9 (the forward conv's geometry)."""
+    dy2 = dy.reshape(-1, dy.shape[-1]) if dy.dim() != 2 else dy
+    x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+    assert dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.dtype == x2.dtype
+    M = M if M is not None else dy2.shape[0]
+    n = n if n is not None else dy2.shape[1]
+    kc = kc if kc is not None else x2.shape[1]
+    nb = max(1, batch) * max(1, batch2)
+    if out is None:
+        out = torch.empty(nb, n, taps, kc, dtype=torch.float32, device=dy.device)
+        assert not accumulate
+    a = L.GemmTnArgs()
+    a.A, a.B, a.out = dy2.data_ptr(), x2.data_ptr(), out.data_ptr()
+    a.a_elems = dy2.numel() if dy2.is_contiguous() else (dy2.shape[0] - 1) * dy2.stride(0) + dy2.shape[1]
+    a.b_elems = x2.numel() if x2.is_contiguous() else (x2.shape[0] - 1) * x2.stride(0) + x2.shape[1]
+    if nb > 1:   # batched problems address beyond one matrix: the extents are those of the whole buffers
+        a.a_elems = dy.numel() if dy.is_contiguous() else a.a_elems
+        a.b_elems = x.numel() if x.is_contiguous() else a.b_elems
+    a.M, a.N, a.Kc = M, n, kc
+    a.lda = lda if lda is not None else dy2.stride(0)
+    a.ldb = ldb if ldb is not None else x2.stride(0)
+    a.taps = taps
+    if taps == 9:
+        a.Hi, a.Wi, a.Ho, a.Wo, a.stride, a.pad, a.ups = [int(v) for v in geom]
+    a.batch, a.batch2 = batch, batch2
+    a.strideA, a.strideB, a.strideA2, a.strideB2 = [int(v) for v in strides]
+    a.ldo_n, a.ldo_t, a.ldo_b = [int(v) for v in out_strides]
+    a.scale, a.accumulate, a.dtype = scale, int(accumulate), _dt(dy2)
+    lib = L.lib()
+    nbytes = lib.dfw_gemm_tn_workspace_bytes(C.byref(a))
+    if nbytes == 0:
+        L.check(lib.dfw_gemm_tn(C.byref(a), _stream()), "dfw_gemm_tn")   # reports the argument error
+    ws = _ws(nbytes, dy.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_gemm_tn(C.byref(a), _stream()), "dfw_gemm_tn")
+    return out
+
+
+def colsum(x, segs=1, out=None, accumulate=False, scale=1.0):
+    """Column sums of x [rows, N] (storage dtype) per segment of rows / segs rows -> fp32 [segs, N]."""
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.stride(1) == 1
+    rows, N = x2.shape
+    assert rows % segs == 0
+    if out is None:
+        out = torch.empty(segs, N, dtype=torch.float32, device=x.device)
+        assert not accumulate
+    ldo = out.stride(0) if out.dim() == 2 else N
+    lib = L.lib()
+    nbytes = lib.dfw_colsum_workspace_bytes(rows // segs, segs, N)
+    ws = _ws(nbytes, x.device)
+    L.check(lib.dfw_colsum(x2.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, rows // segs, segs, N, x2.stride(0), ldo,
+                           float(scale), int(accumulate), _dt(x2), _stream()), "dfw_colsum")
+    return out
+
+
+def groupnorm_bwd(x, dy, mean_rstd, gamma, beta, groups, silu, dgamma=None, dbeta=None, accumulate=False, grad_scale=1.0):
+    """-> dx (like x).  x, dy NHWC (or [B, HW, C]) contiguous; mean_rstd [B, groups, 2] fp32 from the forward."""
+    assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dtype == dy.dtype
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    dx = torch.empty_like(x)
+    a = L.GroupNormBwdArgs()
+    a.x, a.dy, a.dx = x.data_ptr(), dy.data_ptr(), dx.data_ptr()
+    a.gamma, a.beta, a.mean_rstd = _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")), mean_rstd.data_ptr()
+    a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
+    a.B, a.HW, a.C, a.groups, a.ldx, a.lddy, a.lddx = B, HW, Cc, groups, Cc, Cc, Cc
+    a.silu, a.accumulate, a.grad_scale, a.dtype = int(silu), int(accumulate), grad_scale, _dt(x)
+    lib = L.lib()
+    nbytes = lib.dfw_groupnorm_bwd_workspace_bytes(C.byref(a))
+    ws = _ws(nbytes, x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_groupnorm_bwd(C.byref(a), _stream()), "dfw_groupnorm_bwd")
+    return dx
+
+
+def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5, accumulate=False, grad_scale=1.0):
+    assert x.dim() == 2 and dy.shape == x.shape and x.stride(1) == 1 and dy.stride(1) == 1
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    a = L.LayerNormBwdArgs()
+    a.x, a.dy, a.dx, a.gamma = x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _p(_f32(gamma, "gamma"))
+    a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    a.rows, a.C, a.ldx, a.lddy, a.lddx = x.shape[0], x.shape[1], x.stride(0), dy.stride(0), dx.stride(0)
+    a.eps, a.accumulate, a.grad_scale, a.dtype = eps, int(accumulate), grad_scale, _dt(x)
+    lib = L.lib()
+    nbytes = lib.dfw_layernorm_bwd_workspace_bytes(x.shape[0], x.shape[1])
+    ws = _ws(nbytes, x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_layernorm_bwd(C.byref(a), _stream()), "dfw_layernorm_bwd")
+    return dx
+
+
+def geglu_fwd(pre):
+    """pre [rows, 2H] in the packed column order (packing.pack_geglu) -> [rows, H]."""
+    assert pre.dim() == 2 and pre.is_contiguous()
+    rows, H2 = pre.shape
+    out = torch.empty(rows, H2 // 2, dtype=pre.dtype, device=pre.device)
+    L.check(L.lib().dfw_geglu(pre.data_ptr(), None, out.data_ptr(), rows, H2 // 2, _dt(pre), _stream()), "dfw_geglu")
+    return out
+
+
+def geglu_bwd(pre, dout):
+    assert pre.is_contiguous() and dout.is_contiguous() and dout.shape == (pre.shape[0], pre.shape[1] // 2)
+    dpre = torch.empty_like(pre)
+    L.check(L.lib().dfw_geglu(pre.data_ptr(), dout.data_ptr(), dpre.data_ptr(), pre.shape[0], pre.shape[1] // 2, _dt(pre),
+                              _stream()), "dfw_geglu")
+    return dpre
+
+
+def _ew(mode, a, b, y, rows, Cc, lda=0, c0=0, H=0, W=0):
+    L.check(L.lib().dfw_elementwise(mode, a.data_ptr(), _p(b), y.data_ptr(), rows, Cc, lda, c0, H, W, _dt(a), _stream()),
+            "dfw_elementwise")
+    return y
+
+
+def add(a, b):
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+    Cc = a.shape[-1]
+    return _ew(0, a, b, torch.empty_like(a), a.numel() // Cc, Cc)
+
+
+def slice_channels(a, c0, Cc):
+    """a[..., c0:c0+Cc] as a contiguous tensor (backward of concat_channels)."""
+    assert a.is_contiguous()
+    y = torch.empty(*a.shape[:-1], Cc, dtype=a.dtype, device=a.device)
+    return _ew(1, a, None, y, a.numel() // a.shape[-1], Cc, lda=a.shape[-1], c0=c0)
+
+
+def zero_stuff2x(a):
+    """[B, H, W, C] -> [B, 2H, 2W, C] with a at the even positions, zeros elsewhere."""
+    assert a.is_contiguous() and a.dim() == 4
+    B, H, W, Cc = a.shape
+    y = torch.empty(B, 2 * H, 2 * W, Cc, dtype=a.dtype, device=a.device)
+    return _ew(2, a, None, y, B * 4 * H * W, Cc, H=H, W=W)
+
+
+def pool2x2_sum(a):
+    """[B, 2H, 2W, C] -> [B, H, W, C], sums of the 2x2 blocks (backward of the nearest-2x upsample)."""
+    assert a.is_contiguous() and a.dim() == 4
+    B, H2, W2, Cc = a.shape
+    y = torch.empty(B, H2 // 2, W2 // 2, Cc, dtype=a.dtype, device=a.device)
+    return _ew(3, a, None, y, B * (H2 // 2) * (W2 // 2), Cc, H=H2 // 2, W=W2 // 2)
+
+
+def nchw_to_nhwc(x, dtype, cp=8, scale=1.0):
+    """NCHW fp32 -> NHWC `dtype` with channels zero-padded to cp."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, cp, dtype=dtype, device=x.device)
+    L.check(L.lib().dfw_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, Cc, H * W, cp, float(scale), L.BF16 if dtype == torch.bfloat16 else L.F16,
+                                     _stream()), "dfw_nchw_to_nhwc")
+    return y
+
+
+def mse_loss(pred, target, dtype, loss_scale=1.0):
+    """-> (loss fp32 scalar tensor, dpred NHWC [B, H, W, 8] in `dtype`, = 2 (pred - target) / numel * loss_scale)."""
+    assert pred.shape == target.shape and pred.dtype == torch.float32 and pred.is_contiguous() and target.is_contiguous()
+    B, Cc, H, W = pred.shape
+    dpred = torch.zeros(B, H, W, 8, dtype=dtype, device=pred.device)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    ws = torch.empty(256, dtype=torch.float32, device=pred.device)
+    L.check(L.lib().dfw_mse_loss(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), loss.data_ptr(), ws.data_ptr(), B, Cc,
+                                 H * W, float(loss_scale), L.BF16 if dtype == torch.bfloat16 else L.F16, _stream()), "dfw_mse_loss")
+    return loss, dpred
+
+
+def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None):
+    """qkv [B, N, 3C] (q pre-scaled), out / dout [B, N, C], lse [B, heads, N] -> dqkv [B, N, 3C]."""
+    B, N, C3 = qkv.shape
+    Cq = heads * 64
+    assert C3 == 3 * Cq and qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
+    assert out.shape == (B, N, Cq) and dout.shape == out.shape and lse.shape == (B, heads, N) and lse.dtype == torch.float32
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+    a = L.FsaBwdArgs()
+    a.qkv, a.out, a.dout, a.lse, a.delta, a.dqkv = qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr()
+    a.batch, a.heads, a.n, a.nshot, a.n_plain = B, heads, N, nshot, n_plain
+    a.ld, a.ldo, a.ldd = C3, Cq, C3
+    a.scale = scale if scale is not None else 64 ** -0.5
+    a.dtype = _dt(qkv)
+    L.check(L.lib().dfw_fsa_attention_bwd(C.byref(a), _stream()), "dfw_fsa_attention_bwd")
+    return dqkv
+
+
+def sumsq(x):
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    L.check(L.lib().dfw_sumsq(x.data_ptr(), out.data_ptr(), ws.data_ptr(), x.numel(), _stream()), "dfw_sumsq")
+    return out
+
+
+def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_sumsq=None,
+          max_grad_norm=0.0):
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    a = L.AdamWArgs()
+    a.param, a.grad, a.exp_avg, a.exp_avg_sq = param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
+    a.grad_sumsq = _p(grad_sumsq)
+    a.n, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = param.numel(), lr, betas[0], betas[1], eps, weight_decay
+    a.max_grad_norm, a.step = max_grad_norm, step
+    L.check(L.lib().dfw_adamw(C.byref(a), _stream()), "dfw_adamw")

@@ -34,3 +34,17 @@ def pack_geglu(w, b):
     """GEGLU proj weight [2*H, C] / bias [2*H] -> row-interleaved copies (see geglu_perm)."""
     perm = geglu_perm(w.shape[0] // 2)
     return w[perm].contiguous(), b.float()[perm].contiguous()
+
+
+def pack_conv3x3_dgrad(w):
+    """[Cout, Cin, 3, 3] -> [Cin, 9*Cout]: the weight of the conv that computes the DATA gradient of a stride-1
+    conv3x3 (dX = conv3x3(dY, W') with W'[ci][ky][kx][co] = W[co][ci][2-ky][2-kx]: taps mirrored, channels swapped)."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, 9 * co).contiguous()
+
+
+def unpack_conv3x3_grad(g):
+    """packed gradient [Cout, 9, Cin] (dfw_gemm_tn, taps = 9) -> diffusers layout [Cout, Cin, 3, 3]."""
+    co, _, ci = g.shape
+    return g.reshape(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()

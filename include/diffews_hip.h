@@ -128,6 +128,9 @@ typedef struct {
   /* != 0: q already carries the factor scale * log2(e) (dfw_gemm_args.colscale on the projection that
    * produced it); `scale` is then ignored and the kernel exponentiates with exp2(q.k - m) directly. */
   int32_t q_prescaled;
+  /* Optional (training): lse[batch][heads][n_q] fp32 = log2 of the row's sum of exp2(scaled score), so that
+   * exp2(scaled score - lse) is the attention probability -- what dfw_fsa_attention_bwd recomputes P from. */
+  float* lse;
 } dfw_fsa_args;
 
 int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream);
@@ -294,6 +297,125 @@ int dfw_image_to_tensor(const dfw_image_args* a, dfw_stream_t stream);
  * dst_pm1 [3][out_h][out_w] fp32 in (-1,+1) and/or dst_bin [out_h][out_w] uint8 in (0,1). */
 int dfw_mask_to_tensor(const void* mask, int32_t elem_bytes, int32_t H, int32_t W, int32_t class_value,
                        int32_t out_h, int32_t out_w, float* dst_pm1, uint8_t* dst_bin, dfw_stream_t stream);
+
+/* ======================================================================================================
+ * Training step (BASELINE configs[4]; train_tools/train_icl_multitask_nocrop_nearest_nshot_v3.py:1374-1396 =
+ * T): backward of the UNet's ops.  Data gradients of Linear / conv3x3 are dfw_gemm calls with transposed /
+ * tap-mirrored weights; everything else is below.  All reductions are deterministic (fp32 slabs folded in a
+ * fixed order).  `accumulate` != 0 adds into the output gradient (gradient accumulation, T:1323), else
+ * overwrites; `scale` / `grad_scale` multiply parameter gradients (1 / loss scale of fp16 training).
+ * ====================================================================================================== */
+
+/* Weight gradient on MFMA: out[b][n][tap][k] (+)= scale * sum_m A[m][n] * B[row(m, tap)][k]
+ *   taps == 1: dW = dY^T X for nn.Linear (A = dY [M][lda], B = X [M][ldb]; torch autograd of A:237-245, A:276);
+ *   taps == 9: dW[Cout][ky][kx][Cin] of a conv3x3 (A = dY NHWC rows, B = the conv's NHWC input gathered with the
+ *              forward's stride / pad / fused nearest-2x upsample), the packed layout dfw_gemm consumes.
+ * batch / batch2: independent problems at element strides strideA/strideB (and strideA2/strideB2).
+ * out strides in floats: ldo_n (0 => taps*Kc), ldo_t (0 => Kc), ldo_b (0 => N*taps*Kc).
+ * workspace: dfw_gemm_tn_workspace_bytes() (split-M slabs). N, Kc, lda, ldb multiples of 8. */
+typedef struct {
+  const void* A; const void* B; float* out;
+  void* workspace; size_t workspace_bytes;
+  int64_t a_elems, b_elems;
+  int32_t M, N, Kc, lda, ldb;
+  int32_t taps, Hi, Wi, Ho, Wo, stride, pad, ups;
+  int32_t batch, batch2; int64_t strideA, strideB, strideA2, strideB2;
+  int64_t ldo_n, ldo_t, ldo_b;
+  float scale; int32_t accumulate;
+  int32_t dtype;
+} dfw_gemm_tn_args;
+
+int dfw_gemm_tn(const dfw_gemm_tn_args* a, dfw_stream_t stream);
+size_t dfw_gemm_tn_workspace_bytes(const dfw_gemm_tn_args* a);
+
+/* Column sums: out[seg * ldo + n] (+)= scale * sum_{r < rows_per_seg} x[(seg * rows_per_seg + r) * ldx + n].
+ * Bias gradients (segs = 1) and the gradient of the per-image time-embedding projection added in
+ * ResnetBlock2D (segment = image).  workspace: dfw_colsum_workspace_bytes(). */
+int dfw_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t rows_per_seg, int32_t segs,
+               int32_t N, int32_t ldx, int64_t ldo, float scale, int32_t accumulate, int32_t dtype, dfw_stream_t stream);
+size_t dfw_colsum_workspace_bytes(int64_t rows_per_seg, int32_t segs, int32_t N);
+
+/* GroupNorm(+SiLU) backward (torch.nn.GroupNorm + F.silu under autograd; ResnetBlock2D.norm1/norm2,
+ * Transformer2DModel.norm, conv_norm_out).  mean_rstd [B][groups][2] are the forward's statistics
+ * (the tail of dfw_groupnorm's stats_ws).  dgamma / dbeta may be NULL. */
+typedef struct {
+  const void* x; const void* dy; void* dx; const float* gamma; const float* beta; const float* mean_rstd;
+  float* dgamma; float* dbeta;
+  void* workspace; size_t workspace_bytes;
+  int32_t B, HW, C, groups, ldx, lddy, lddx;
+  int32_t silu, accumulate;
+  float grad_scale;
+  int32_t dtype;
+} dfw_groupnorm_bwd_args;
+
+int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t stream);
+size_t dfw_groupnorm_bwd_workspace_bytes(const dfw_groupnorm_bwd_args* a);
+
+/* LayerNorm backward (BasicTransformerBlock.norm1/2/3); statistics are recomputed from x. */
+typedef struct {
+  const void* x; const void* dy; void* dx; const float* gamma; float* dgamma; float* dbeta;
+  void* workspace; size_t workspace_bytes;
+  int32_t rows, C, ldx, lddy, lddx;
+  float eps;
+  int32_t accumulate;
+  float grad_scale;
+  int32_t dtype;
+} dfw_layernorm_bwd_args;
+
+int dfw_layernorm_bwd(const dfw_layernorm_bwd_args* a, dfw_stream_t stream);
+size_t dfw_layernorm_bwd_workspace_bytes(int32_t rows, int32_t C);
+
+/* GEGLU on the packed column order (see dfw_gemm_args.geglu): pre [rows][2H].
+ * dout == NULL: forward, out [rows][H] = value * gelu(gate); else backward, out = d(pre) [rows][2H]. */
+int dfw_geglu(const void* pre, const void* dout, void* out, int64_t rows, int32_t H, int32_t dtype, dfw_stream_t stream);
+
+/* Data movement of the backward graph, C % 8 == 0:
+ *   mode 0  y = a + b                                  [rows][C]    (a tensor consumed twice: residual, skip)
+ *   mode 1  y = a[:, c0 : c0 + C], a has lda columns     (backward of torch.cat([h, skip], 1), U:1226)
+ *   mode 2  y[B][2H][2W][C]: y[2i][2j] = a[i][j], else 0  (rows = B*2H*2W; stride-2 conv data gradient)
+ *   mode 3  y[B][H][W][C] = 2x2 block sums of a[B][2H][2W][C]  (rows = B*H*W; fused nearest-2x upsample) */
+int dfw_elementwise(int32_t mode, const void* a, const void* b, void* y, int64_t rows, int32_t C, int32_t lda,
+                    int32_t c0, int32_t H, int32_t W, int32_t dtype, dfw_stream_t stream);
+
+/* NCHW fp32 [B][C][HW] -> NHWC storage dtype [B][HW][Cp], channels zero-padded to Cp, times scale
+ * (the UNet's latent inputs as the B operand of the conv_in weight gradient). */
+int dfw_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t HW, int32_t Cp, float scale, int32_t dtype,
+                     dfw_stream_t stream);
+
+/* loss = mean((pred - target)^2) (F.mse_loss, T:1384; pred/target NCHW fp32 [B][C][HW], C <= 8) and
+ * dpred = 2 (pred - target) / numel * loss_scale as NHWC storage dtype [B][HW][8] (zero-initialised by the
+ * caller: channels C..7 are not written).  workspace: 256 floats. */
+int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* loss, float* workspace, int32_t B, int32_t C,
+                 int32_t HW, float loss_scale, int32_t dtype, dfw_stream_t stream);
+
+/* KV-fusion attention backward for the lock-step batch (dfw_fsa_args.n_plain form; nshot == 0: plain
+ * self-attention).  qkv [batch][n][ld >= 3C]: the fused projection output with q PRE-SCALED
+ * (dfw_gemm_args.colscale); out / dout [batch][n][ldo]; lse from the forward; delta [batch][heads][n] is
+ * scratch.  dqkv [batch][n][ldd >= 3C] receives (dq, dk, dv) with dq taken with respect to the UNSCALED
+ * projection output, so it is the dY of the QKV Linear as is.  scale = attn.scale (A:269-271). */
+typedef struct {
+  const void* qkv; const void* out; const void* dout; const float* lse; float* delta; void* dqkv;
+  int32_t batch, heads, n, nshot, n_plain;
+  int32_t ld, ldo, ldd;
+  float scale;
+  int32_t dtype;
+} dfw_fsa_bwd_args;
+
+int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream);
+
+/* Sum of squares of an fp32 vector (the global gradient norm of clip_grad_norm_, T:1393); workspace: 1024 floats. */
+int dfw_sumsq(const float* x, float* out, float* workspace, int64_t n, dfw_stream_t stream);
+
+/* AdamW step on flat fp32 tensors (torch.optim.AdamW, T:1186-1194), with the clip factor
+ * min(1, max_grad_norm / (sqrt(*grad_sumsq) + 1e-6)) applied to the gradient when grad_sumsq != NULL. */
+typedef struct {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq; const float* grad_sumsq;
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
+  int32_t step;
+} dfw_adamw_args;
+
+int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream);
 
 #ifdef __cplusplus
 }

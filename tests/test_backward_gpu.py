@@ -1,0 +1,243 @@
+"""Per-op parity of the training step's backward kernels (BASELINE configs[4]) against torch
+autograd of the same op in fp32 on the same (storage-dtype-rounded) inputs.
+
+Tolerances, relative L2: gradients that are fp32 sums of exact 16-bit products (weight / bias gradients, column
+sums, loss) 2e-5; gradients stored in the storage dtype or passing through 16-bit intermediates: TOL[dtype].
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def B(hip_lib):
+    from diffews_amd import ops, ops_bwd
+    return ops, ops_bwd
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (1000, 64, 1280), (8, 1280, 320), (50000, 8, 128), (333, 640, 64)])
+def test_linear_wgrad(B, dtype, M, N, K):
+    """dW = dY^T X (nn.Linear weight gradient): ragged M (zero-filled rows), tiny M (the time-embedding MLP, one
+    row per image), N = 8 (padded conv_out channels)."""
+    ops, ob = B
+    dy, x = rnd((M, N), dtype, 1), rnd((M, K), dtype, 2)
+    ref = dy.float().t() @ x.float()
+    g = ob.gemm_tn(dy.cuda(), x.cuda())
+    assert g.shape == (1, N, 1, K) and rel(g.view(N, K), ref) < 2e-5
+    acc = torch.ones(1, N, 1, K, device="cuda")
+    ob.gemm_tn(dy.cuda(), x.cuda(), out=acc, accumulate=True, scale=0.5)
+    assert rel(acc.view(N, K), 1 + 0.5 * ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Bn,H,W,Cin,Cout,stride,ups", [(2, 16, 16, 64, 128, 1, 0), (1, 24, 40, 128, 64, 1, 0),
+                                                      (2, 16, 16, 64, 64, 2, 0), (1, 8, 8, 64, 128, 1, 1),
+                                                      (3, 4, 4, 128, 128, 1, 0)])
+def test_conv3x3_backward(B, dtype, Bn, H, W, Cin, Cout, stride, ups):
+    """Weight gradient (TN GEMM over the forward's im2col addressing) and data gradient (the forward conv kernel
+    on mirrored weights; stride 2 through zero-stuffing, the fused upsample through 2x2 pooling) of every conv
+    form in the UNet (ResnetBlock2D convs, Downsample2D stride 2 pad 1, Upsample2D nearest-2x + conv)."""
+    ops, ob = B
+    from diffews_amd.packing import pack_conv3x3, pack_conv3x3_dgrad, unpack_conv3x3_grad
+    x = rnd((Bn, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    xin = F.interpolate(xr, scale_factor=2.0, mode="nearest") if ups else xr
+    y = F.conv2d(xin, wr, None, stride=stride, padding=1)
+    dy = rnd(tuple(y.shape), dtype, 3)
+    y.backward(dy.float())
+    Ho, Wo = y.shape[-2:]
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    gw = ob.gemm_tn(dyh, xh, taps=9, geom=(H, W, Ho, Wo, stride, 1, ups))
+    assert rel(unpack_conv3x3_grad(gw.view(Cout, 9, Cin)), wr.grad) < 2e-5
+    wd = pack_conv3x3_dgrad(w).cuda()
+    if stride == 2:
+        dx = ops.conv3x3(ob.zero_stuff2x(dyh), wd, Cin)
+    elif ups:
+        dx = ob.pool2x2_sum(ops.conv3x3(dyh, wd, Cin))
+    else:
+        dx = ops.conv3x3(dyh, wd, Cin)
+    assert dx.shape == (Bn, H, W, Cin) and rel(dx.permute(0, 3, 1, 2), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_dgrad_and_colsum(B, dtype):
+    ops, ob = B
+    M, N, K = 3000, 640, 320
+    dy, w = rnd((M, N), dtype, 1), rnd((N, K), dtype, 2, N ** -0.5)
+    dx = ops.linear(dy.cuda(), w.t().contiguous().cuda())       # dX = dY W: the forward kernel on W^T
+    assert rel(dx, dy.float() @ w.float()) < TOL[dtype]
+    assert rel(ob.colsum(dy.cuda()).view(-1), dy.float().sum(0)) < 2e-5
+    per_img = ob.colsum(dy.cuda(), segs=3)                      # per-image sums: d(time-embedding projection)
+    assert rel(per_img, dy.float().view(3, 1000, N).sum(1)) < 2e-5
+    acc = torch.full((1, N), 2.0, device="cuda")
+    ob.colsum(dy.cuda(), out=acc, accumulate=True, scale=0.25)
+    assert rel(acc.view(-1), 2 + 0.25 * dy.float().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("Bn,HW,C", [(2, 256, 64), (3, 100, 320), (1, 4096, 128), (2, 4, 1280)])
+def test_groupnorm_backward(B, dtype, silu, Bn, HW, C):
+    ops, ob = B
+    G = 32
+    x, dy = rnd((Bn, HW, C), dtype, 1) + 0.5, rnd((Bn, HW, C), dtype, 2)
+    gamma, beta = torch.randn(C) * 0.5 + 1.0, torch.randn(C) * 0.2
+    xr, gr, br = x.float().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    z = F.group_norm(xr.transpose(1, 2), G, gr, br, 1e-5).transpose(1, 2)
+    (F.silu(z) if silu else z).backward(dy.float())
+    y, mr = ops.groupnorm(x.cuda(), gamma.cuda(), beta.cuda(), G, 1e-5, silu=silu, return_stats=True)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ob.groupnorm_bwd(x.cuda(), dy.cuda(), mr, gamma.cuda(), beta.cuda(), G, silu, dg, db)
+    assert rel(dx, xr.grad) < 2 * TOL[dtype]
+    assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 2e-3      # fp32 sums of fp32 terms (xhat from 16-bit x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(4096, 320), (777, 640), (64, 1280), (5, 64)])
+def test_layernorm_backward(B, dtype, rows, C):
+    ops, ob = B
+    x, dy = rnd((rows, C), dtype, 1) + 0.3, rnd((rows, C), dtype, 2)
+    gamma, beta = torch.randn(C) * 0.5 + 1.0, torch.randn(C) * 0.2
+    xr, gr, br = x.float().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    F.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy.float())
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ob.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), dg, db)
+    assert rel(dx, xr.grad) < TOL[dtype]
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu_forward_backward(B, dtype):
+    """Packed-column GEGLU (packing.pack_geglu) == x * gelu(gate) of diffusers' GEGLU, forward and backward."""
+    ops, ob = B
+    from diffews_amd.packing import geglu_perm
+    rows, H = 500, 256
+    pre = rnd((rows, 2 * H), dtype, 1)                      # natural order: [value | gate]
+    perm = geglu_perm(H)
+    packed = pre[:, perm].contiguous()
+    pr = pre.float().requires_grad_()
+    a, g = pr.chunk(2, dim=-1)
+    out = a * F.gelu(g)
+    dout = rnd((rows, H), dtype, 2)
+    out.backward(dout.float())
+    ff = ob.geglu_fwd(packed.cuda())
+    assert rel(ff, out) < TOL[dtype]
+    dpre = ob.geglu_bwd(packed.cuda(), dout.cuda())
+    assert rel(dpre, pr.grad[:, perm]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise_and_loss(B, dtype):
+    ops, ob = B
+    a, b = rnd((2, 6, 10, 64), dtype, 1), rnd((2, 6, 10, 64), dtype, 2)
+    assert rel(ob.add(a.cuda(), b.cuda()), a.float() + b.float()) < TOL[dtype]
+    wide = rnd((2, 6, 10, 192), dtype, 3)
+    assert torch.equal(ob.slice_channels(wide.cuda(), 64, 128).cpu(), wide[..., 64:192])
+    z = ob.zero_stuff2x(a.cuda()).cpu()
+    assert z.shape == (2, 12, 20, 64) and torch.equal(z[:, ::2, ::2], a) and float(z.float().abs().sum()) == float(a.float().abs().sum())
+    big = rnd((2, 12, 20, 64), dtype, 4)
+    ref = big.float().view(2, 6, 2, 10, 2, 64).sum((2, 4))
+    assert rel(ob.pool2x2_sum(big.cuda()), ref) < TOL[dtype]
+    lat = torch.randn(3, 4, 8, 8)
+    nh = ob.nchw_to_nhwc(lat.cuda(), dtype, cp=8).cpu()
+    assert nh.shape == (3, 8, 8, 8) and torch.equal(nh[..., :4], lat.permute(0, 2, 3, 1).to(dtype)) and float(nh[..., 4:].abs().sum()) == 0
+    pred, tgt = torch.randn(2, 4, 16, 16), torch.randn(2, 4, 16, 16)
+    pr = pred.clone().requires_grad_()
+    l = F.mse_loss(pr, tgt)
+    l.backward()
+    loss, dpred = ob.mse_loss(pred.cuda(), tgt.cuda(), dtype, loss_scale=8.0)
+    assert abs(float(loss) - float(l)) < 1e-5 * float(l)
+    assert rel(dpred[..., :4].permute(0, 3, 1, 2), 8.0 * pr.grad) < TOL[dtype] and float(dpred[..., 4:].abs().sum()) == 0
+
+
+def test_adamw_and_clip_match_torch(B):
+    """One fused AdamW step on a flat fp32 vector == torch.optim.AdamW after clip_grad_norm_ (T:1186-1194, T:1393)."""
+    ops, ob = B
+    n = 100_003
+    g = torch.Generator().manual_seed(0)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    tp = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([tp], lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    pc, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in (1, 2, 3):
+        tp.grad = gr.clone() * step
+        torch.nn.utils.clip_grad_norm_([tp], 1.0)
+        opt.step()
+        gc = (gr * step).cuda()
+        ss = ob.sumsq(gc)
+        assert abs(float(ss) - float((gr * step).pow(2).sum())) < 1e-4 * float(ss)
+        ob.adamw(pc, gc, m, v, step, 3e-4, grad_sumsq=ss, max_grad_norm=1.0)
+        assert rel(pc, tp.detach()) < 1e-6
+
+
+def _attn_ref(qkv, heads, b, nshot):
+    """fp32 autograd reference of the lock-step KV-fusion attention: image i < b*nshot (support) attends over its own
+    keys; query image j over [own ; its episode's support images] (A:251-267)."""
+    from diffews_amd.ops import FSA_QSCALE
+    n_ref = b * nshot
+    Bt, N, C3 = qkv.shape
+    C = C3 // 3
+    x = qkv.float().requires_grad_()
+    q, k, v = x[..., :C] / FSA_QSCALE, x[..., C:2 * C], x[..., 2 * C:]          # q back to unscaled units
+    sh = lambda t: t.reshape(t.shape[0], -1, heads, 64).transpose(1, 2)
+    outs = []
+    if n_ref:
+        outs.append(F.scaled_dot_product_attention(sh(q[:n_ref]), sh(k[:n_ref]), sh(v[:n_ref])).transpose(1, 2).reshape(n_ref, N, C))
+    for j in range(Bt - n_ref):
+        kk, vv = k[n_ref + j:n_ref + j + 1], v[n_ref + j:n_ref + j + 1]
+        if nshot:
+            kk = torch.cat([kk, k[j * nshot:(j + 1) * nshot].reshape(1, nshot * N, C)], 1)
+            vv = torch.cat([vv, v[j * nshot:(j + 1) * nshot].reshape(1, nshot * N, C)], 1)
+        outs.append(F.scaled_dot_product_attention(sh(q[n_ref + j:n_ref + j + 1]), sh(kk), sh(vv)).transpose(1, 2).reshape(1, N, C))
+    return x, torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,nshot,heads,N", [(2, 0, 1, 64), (1, 1, 2, 256), (2, 2, 1, 100), (1, 3, 2, 200), (2, 1, 5, 64)])
+def test_fsa_attention_backward(B, dtype, b, nshot, heads, N):
+    """Forward with the per-row log-sum-exp + the two flash backward kernels vs torch autograd: dq / dk / dv of the
+    lock-step batch, the support images' dk / dv collecting BOTH their own pass and their episode's query pass."""
+    ops, ob = B
+    from diffews_amd.ops import FSA_QSCALE
+    n_ref, C = b * nshot, heads * 64
+    Bt = n_ref + b
+    qkv = rnd((Bt, N, 3 * C), dtype, 5)
+    qkv[..., :C] = (qkv[..., :C].float() * FSA_QSCALE * 2).to(dtype)      # pre-scaled q
+    x, out_ref = _attn_ref(qkv, heads, b, nshot)
+    dout = rnd((Bt, N, C), dtype, 6)
+    out_ref.backward(dout.float())
+    dref = x.grad.clone()
+    dref[..., :C] = dref[..., :C] * FSA_QSCALE      # the reference's gradient is w.r.t. the PRE-SCALED q: undo -> d(unscaled)
+    qg = qkv.cuda()
+    q, k, v = qg[..., :C], qg[..., C:2 * C], qg[..., 2 * C:]
+    lse = torch.empty(Bt, heads, N, dtype=torch.float32, device="cuda")
+    if nshot:
+        out = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=nshot, n_plain=n_ref, q_prescaled=True, lse=lse)
+    else:
+        out = ops.fsa_attention(q, k, v, heads, q_prescaled=True, lse=lse)
+    assert rel(out, out_ref) < 1.5 * TOL[dtype]
+    dqkv = ob.fsa_attention_bwd(qg, out, dout.cuda(), lse, heads, nshot=nshot, n_plain=n_ref)
+    want_q = dref[..., :C]          # d(unscaled projection output) = QSCALE * d(q_pre), converted above
+    assert rel(dqkv[..., C:2 * C], dref[..., C:2 * C]) < 2 * TOL[dtype], "dk"
+    assert rel(dqkv[..., 2 * C:], dref[..., 2 * C:]) < 2 * TOL[dtype], "dv"
+    assert rel(dqkv[..., :C], want_q) < 2 * TOL[dtype], "dq"
