@@ -98,6 +98,15 @@ class FsaBwdArgs(C.Structure):
                 ("ld", _i32), ("ldo", _i32), ("ldd", _i32), ("scale", _f32), ("dtype", _i32)]
 
 
+class XattnBwdArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("dout", _vp), ("dq", _vp), ("dk", _vp), ("dv", _vp),
+                ("workspace", _vp), ("workspace_bytes", _sz),
+                ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("L", _i32),
+                ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32), ("lddq", _i32), ("lddkv", _i32),
+                ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("o_bs", _i64), ("dq_bs", _i64), ("dkv_bs", _i64),
+                ("scale", _f32), ("dtype", _i32)]
+
+
 class AdamWArgs(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_sumsq", _vp), ("n", _i64),
                 ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_grad_norm", _f32),
@@ -139,8 +148,11 @@ SYMBOLS = {
     "dfw_geglu": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "dfw_elementwise": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dfw_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
-    "dfw_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dfw_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_fsa_attention_bwd": (_i32, [C.POINTER(FsaBwdArgs), _vp]),
+    "dfw_cross_attention_bwd": (_i32, [C.POINTER(XattnBwdArgs), _vp]),
+    "dfw_cross_attention_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "dfw_silu": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "dfw_sumsq": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "dfw_adamw": (_i32, [C.POINTER(AdamWArgs), _vp]),
     "dfw_resample_ksize": (_i32, [_i32, _i32]),

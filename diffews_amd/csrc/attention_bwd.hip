@@ -342,9 +342,199 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ attn2 backward
+// Cross-attention over a short context (L prompt tokens; 77 in training, T:1368): VALU kernel like the forward.
+// Workgroup = 64 query rows of one (image, head).  Phase 1: one thread per row recomputes p = softmax(q k^T scale),
+// dp = do v^T, ds = p (dp - sum p dp) scale and writes dq; p and ds stay in LDS.  Phase 2: all threads fold the
+// 64 rows into the tile's partial dK[j][d] = sum_r ds[r][j] q[r][d], dV[j][d] = sum_r p[r][j] do[r][d]
+// (fp32, [chunk][L][64] per (image, head)); xattn_bwd_fold_kernel sums the chunks in order and writes the 16-bit
+// gradient of the layer's prompt K / V projection output.
+struct XabP {
+  const char* q; const char* k; const char* v; const char* dout; char* dq; float* part; char* dk; char* dv;
+  int batch, heads, n_q, L, ldq, ldk, ldv, ldo, lddq, lddkv, chunks;
+  long long q_bs, k_bs, v_bs, o_bs, dq_bs, dkv_bs;
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_bwd_kernel(const XabP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_xb[];
+  const int L = p.L, LP = L + 1;
+  float* Ks = (float*)smem_xb;            // [L][64]
+  float* Vs = Ks + (size_t)L * 64;        // [L][64]
+  float* Qs = Vs + (size_t)L * 64;        // [64][65]
+  float* Ds = Qs + 64 * 65;               // [64][65]
+  float* Ps = Ds + 64 * 65;               // [64][LP]
+  float* Ss = Ps + 64 * LP;               // [64][LP]
+  const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  for (int e = threadIdx.x; e < L * 8; e += 256) {
+    const int j = e >> 3, c8 = e & 7;
+    float f[8];
+    unpack8<T>(*(const i32x4*)(p.k + ((size_t)b * p.k_bs + (size_t)j * p.ldk + head * 64 + c8 * 8) * sizeof(T)), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Ks[j * 64 + c8 * 8 + i] = f[i];
+    unpack8<T>(*(const i32x4*)(p.v + ((size_t)b * p.v_bs + (size_t)j * p.ldv + head * 64 + c8 * 8) * sizeof(T)), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Vs[j * 64 + c8 * 8 + i] = f[i];
+  }
+  for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+    const int r = e >> 3, c8 = e & 7, row = chunk * 64 + r;
+    float fq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < p.n_q) {
+      unpack8<T>(*(const i32x4*)(p.q + ((size_t)b * p.q_bs + (size_t)row * p.ldq + head * 64 + c8 * 8) * sizeof(T)), fq);
+      unpack8<T>(*(const i32x4*)(p.dout + ((size_t)b * p.o_bs + (size_t)row * p.ldo + head * 64 + c8 * 8) * sizeof(T)), fd);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { Qs[r * 65 + c8 * 8 + i] = fq[i]; Ds[r * 65 + c8 * 8 + i] = fd[i]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x, row = chunk * 64 + r;
+    float m = -1e30f;
+    for (int j = 0; j < L; ++j) {
+      float sd = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) sd += Qs[r * 65 + i] * Ks[j * 64 + i];
+      sd *= p.scale;
+      Ps[r * LP + j] = sd;
+      m = fmaxf(m, sd);
+    }
+    float l = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float e = __expf(Ps[r * LP + j] - m);
+      Ps[r * LP + j] = e;
+      l += e;
+    }
+    const float inv = 1.0f / l;
+    float delta = 0.f;
+    for (int j = 0; j < L; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) dp += Ds[r * 65 + i] * Vs[j * 64 + i];
+      const float pr = Ps[r * LP + j] * inv;
+      Ps[r * LP + j] = row < p.n_q ? pr : 0.f;
+      Ss[r * LP + j] = dp;
+      delta += pr * dp;
+    }
+    float dq[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) dq[i] = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float ds = row < p.n_q ? Ps[r * LP + j] * (Ss[r * LP + j] - delta) * p.scale : 0.f;
+      Ss[r * LP + j] = ds;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) dq[i] += ds * Ks[j * 64 + i];
+    }
+    if (row < p.n_q) {
+      char* op = p.dq + ((size_t)b * p.dq_bs + (size_t)row * p.lddq + head * 64) * sizeof(T);
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) *(i32x4*)(op + c8 * 16) = pack8<T>(dq + c8 * 8);
+    }
+  }
+  __syncthreads();
+  float* out = p.part + ((((size_t)b * p.heads + head) * p.chunks + chunk) * 2) * (size_t)L * 64;
+  for (int e = threadIdx.x; e < L * 64; e += 256) {
+    const int j = e >> 6, d = e & 63;
+    float ak = 0.f, av = 0.f;
+    for (int r = 0; r < 64; ++r) {
+      ak += Ss[r * LP + j] * Qs[r * 65 + d];
+      av += Ps[r * LP + j] * Ds[r * 65 + d];
+    }
+    out[e] = ak;
+    out[(size_t)L * 64 + e] = av;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_bwd_fold_kernel(const XabP p) {
+  const long long total = (long long)p.batch * p.heads * p.L * 64;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int d = (int)(e & 63);
+    const long long t = e >> 6;
+    const int j = (int)(t % p.L);
+    const long long bh = t / p.L;
+    const int head = (int)(bh % p.heads), b = (int)(bh / p.heads);
+    float ak = 0.f, av = 0.f;
+    for (int c = 0; c < p.chunks; ++c) {
+      const float* o = p.part + (((size_t)bh * p.chunks + c) * 2) * (size_t)p.L * 64 + j * 64 + d;
+      ak += o[0];
+      av += o[(size_t)p.L * 64];
+    }
+    const size_t off = (size_t)b * p.dkv_bs + (size_t)j * p.lddkv + head * 64 + d;
+    ((T*)p.dk)[off] = (T)ak;
+    ((T*)p.dv)[off] = (T)av;
+  }
+}
+
+// y = silu(a) (b == nullptr) or y = b * silu'(a): the SiLU of the timestep-embedding MLP (TimestepEmbedding.act and the
+// F.silu in front of every time_emb_proj), a few thousand elements
+template <typename T>
+__global__ __launch_bounds__(256) void silu_kernel(const T* a, const T* b, T* y, long long n) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const float z = (float)a[e];
+    const float sg = 1.0f / (1.0f + __expf(-z));
+    y[e] = b ? (T)((float)b[e] * sg * (1.0f + z * (1.0f - sg))) : (T)(z * sg);
+  }
+}
+
 }  // namespace dfw
 
 using namespace dfw;
+
+extern "C" size_t dfw_cross_attention_bwd_workspace_bytes(int32_t batch, int32_t heads, int32_t n_q, int32_t L) {
+  if (batch <= 0 || heads <= 0 || n_q <= 0 || L <= 0) return 0;
+  return (size_t)batch * heads * ((n_q + 63) / 64) * 2 * L * 64 * sizeof(float);
+}
+
+extern "C" int dfw_cross_attention_bwd(const dfw_xattn_bwd_args* a, dfw_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->dout || !a->dq || !a->dk || !a->dv || !a->workspace) return DFW_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->L <= 0) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  if ((a->ldq | a->ldk | a->ldv | a->ldo | a->lddq) % 8 != 0) return DFW_ESHAPE;
+  const size_t lds = ((size_t)a->L * 64 * 2 + 2 * 64 * 65 + 2 * 64 * (a->L + 1)) * sizeof(float);
+  if (lds > 150 * 1024) return DFW_ESHAPE;
+  const int chunks = (a->n_q + 63) / 64;
+  if (a->workspace_bytes < dfw_cross_attention_bwd_workspace_bytes(a->batch, a->heads, a->n_q, a->L)) return DFW_EWORKSPACE;
+  XabP p;
+  p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.dout = (const char*)a->dout;
+  p.dq = (char*)a->dq; p.part = (float*)a->workspace; p.dk = (char*)a->dk; p.dv = (char*)a->dv;
+  p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.L = a->L;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.lddq = a->lddq; p.lddkv = a->lddkv; p.chunks = chunks;
+  p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs; p.o_bs = a->o_bs; p.dq_bs = a->dq_bs; p.dkv_bs = a->dkv_bs;
+  p.scale = a->scale;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(chunks, a->heads, a->batch);
+  const long long total = (long long)a->batch * a->heads * a->L * 64;
+  int fg = (int)((total + 255) / 256);
+  if (fg > 2048) fg = 2048;
+  if (a->dtype == DFW_BF16) {
+    auto kfn = xattn_bwd_kernel<__bf16>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL((xattn_bwd_fold_kernel<__bf16>), dim3(fg), dim3(256), 0, st, p);
+  } else {
+    auto kfn = xattn_bwd_kernel<_Float16>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL((xattn_bwd_fold_kernel<_Float16>), dim3(fg), dim3(256), 0, st, p);
+  }
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_silu(const void* a, const void* dy, void* y, int64_t n, int32_t dtype, dfw_stream_t stream) {
+  if (!a || !y || n <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  int g = (int)((n + 255) / 256);
+  if (g > 2048) g = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((silu_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const __bf16*)a, (const __bf16*)dy, (__bf16*)y, (long long)n);
+  else hipLaunchKernelGGL((silu_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const _Float16*)a, (const _Float16*)dy, (_Float16*)y, (long long)n);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream) {
   if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->delta || !a->dqkv) return DFW_EINVAL;

@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, T* y,
 // dpred = 2 (pred - target) / numel * loss_scale, written as NHWC storage dtype [B][H][W][8] (channels padded to
 // 8) for the conv_out backward.  Two-level deterministic reduction of the loss value.
 template <typename T>
-__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, T* dpred, float* part, int B,
-                                                  int C, int HW, float gscale) {
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, T* dpred, float* dnchw, float* part,
+                                                  int B, int C, int HW, float gscale) {
   __shared__ float red[4];
   const long long total = (long long)B * C * HW;
   float acc = 0.f;
@@ -597,7 +597,9 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
     const int p = (int)(e - bc * HW);
     const long long b = bc / C;
     const int c = (int)(bc - b * C);
-    dpred[((size_t)b * HW + p) * 8 + c] = (T)(d * gscale);
+    const T g = (T)(d * gscale);
+    dpred[((size_t)b * HW + p) * 8 + c] = g;
+    if (dnchw) dnchw[e] = (float)g;       // the same (rounded) values, NCHW fp32, for the direct data-gradient conv
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -900,8 +902,9 @@ extern "C" int dfw_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, i
   return 0;
 }
 
-extern "C" int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* loss, float* workspace,
-                            int32_t B, int32_t C, int32_t HW, float loss_scale, int32_t dtype, dfw_stream_t stream) {
+extern "C" int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* dpred_nchw, float* loss,
+                            float* workspace, int32_t B, int32_t C, int32_t HW, float loss_scale, int32_t dtype,
+                            dfw_stream_t stream) {
   if (!pred || !target || !dpred || !loss || !workspace || B <= 0 || C <= 0 || C > 8 || HW <= 0) return DFW_EINVAL;
   if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -909,8 +912,8 @@ extern "C" int dfw_mse_loss(const float* pred, const float* target, void* dpred,
   const int nb = 256;   // workspace: 256 floats
   const float gscale = 2.0f / (float)total * loss_scale;
   // channels C..7 of dpred are never written by the kernel: the caller passes a zero-initialised buffer
-  if (dtype == DFW_BF16) hipLaunchKernelGGL((mse_kernel<__bf16>), dim3(nb), dim3(256), 0, st, pred, target, (__bf16*)dpred, workspace, B, C, HW, gscale);
-  else hipLaunchKernelGGL((mse_kernel<_Float16>), dim3(nb), dim3(256), 0, st, pred, target, (_Float16*)dpred, workspace, B, C, HW, gscale);
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((mse_kernel<__bf16>), dim3(nb), dim3(256), 0, st, pred, target, (__bf16*)dpred, dpred_nchw, workspace, B, C, HW, gscale);
+  else hipLaunchKernelGGL((mse_kernel<_Float16>), dim3(nb), dim3(256), 0, st, pred, target, (_Float16*)dpred, dpred_nchw, workspace, B, C, HW, gscale);
   DFW_CHECK_LAUNCH();
   hipLaunchKernelGGL(fold_scalar_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, loss, nb, 1.0f / (float)total);
   DFW_CHECK_LAUNCH();

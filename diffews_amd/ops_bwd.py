@@ -175,15 +175,21 @@ def nchw_to_nhwc(x, dtype, cp=8, scale=1.0):
     return y
 
 
-def mse_loss(pred, target, dtype, loss_scale=1.0):
-    """-> (loss fp32 scalar tensor, dpred NHWC [B, H, W, 8] in `dtype`, = 2 (pred - target) / numel * loss_scale)."""
+def mse_loss(pred, target, dtype, loss_scale=1.0, dpred_out=None, dpred_nchw_out=None):
+    """-> (loss fp32 tensor [1], dpred NHWC [B, H, W, 8] in `dtype` = 2 (pred - target) / numel * loss_scale).
+    dpred_out: zero-initialised destination (e.g. the query rows of a larger batch); dpred_nchw_out: optional fp32
+    [B, C, H, W] that receives the same rounded values."""
     assert pred.shape == target.shape and pred.dtype == torch.float32 and pred.is_contiguous() and target.is_contiguous()
     B, Cc, H, W = pred.shape
-    dpred = torch.zeros(B, H, W, 8, dtype=dtype, device=pred.device)
+    dpred = dpred_out if dpred_out is not None else torch.zeros(B, H, W, 8, dtype=dtype, device=pred.device)
+    assert dpred.shape == (B, H, W, 8) and dpred.is_contiguous() and dpred.dtype == dtype
+    if dpred_nchw_out is not None:
+        assert dpred_nchw_out.shape == pred.shape and dpred_nchw_out.is_contiguous() and dpred_nchw_out.dtype == torch.float32
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     ws = torch.empty(256, dtype=torch.float32, device=pred.device)
-    L.check(L.lib().dfw_mse_loss(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), loss.data_ptr(), ws.data_ptr(), B, Cc,
-                                 H * W, float(loss_scale), L.BF16 if dtype == torch.bfloat16 else L.F16, _stream()), "dfw_mse_loss")
+    L.check(L.lib().dfw_mse_loss(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), _p(dpred_nchw_out), loss.data_ptr(),
+                                 ws.data_ptr(), B, Cc, H * W, float(loss_scale), L.BF16 if dtype == torch.bfloat16 else L.F16,
+                                 _stream()), "dfw_mse_loss")
     return loss, dpred
 
 
@@ -203,6 +209,38 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     a.dtype = _dt(qkv)
     L.check(L.lib().dfw_fsa_attention_bwd(C.byref(a), _stream()), "dfw_fsa_attention_bwd")
     return dqkv
+
+
+def cross_attention_bwd(q, k, v, dout, heads, dk_out, dv_out, scale=None):
+    """attn2 backward.  q / dout [B, N, heads*64]; k / v [B, L, heads*64] views; dk_out / dv_out: [B, L, heads*64]
+    views (column slices of the fused prompt-K/V gradient buffer) that receive dK / dV.  -> dq [B, N, heads*64]."""
+    B, N, Cq = q.shape
+    Lc = k.shape[1]
+    assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and dout.stride(2) == 1
+    assert dk_out.shape == (B, Lc, Cq) and dv_out.shape == dk_out.shape and dk_out.stride(2) == 1
+    assert dk_out.stride(0) == dv_out.stride(0) and dk_out.stride(1) == dv_out.stride(1)
+    dq = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
+    a = L.XattnBwdArgs()
+    a.q, a.k, a.v, a.dout, a.dq, a.dk, a.dv = q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk_out.data_ptr(), dv_out.data_ptr()
+    a.batch, a.heads, a.n_q, a.L = B, heads, N, Lc
+    a.ldq, a.ldk, a.ldv, a.ldo, a.lddq, a.lddkv = q.stride(1), k.stride(1), v.stride(1), dout.stride(1), Cq, dk_out.stride(1)
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs, a.dq_bs, a.dkv_bs = q.stride(0), k.stride(0), v.stride(0), dout.stride(0), N * Cq, dk_out.stride(0)
+    a.scale = scale if scale is not None else 64 ** -0.5
+    a.dtype = _dt(q)
+    lib = L.lib()
+    nbytes = lib.dfw_cross_attention_bwd_workspace_bytes(B, heads, N, Lc)
+    ws = _ws(nbytes, q.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_cross_attention_bwd(C.byref(a), _stream()), "dfw_cross_attention_bwd")
+    return dq
+
+
+def silu(a, dy=None):
+    """silu(a), or dy * silu'(a) when dy is given (storage dtype, any shape, contiguous)."""
+    assert a.is_contiguous() and (dy is None or (dy.is_contiguous() and dy.shape == a.shape))
+    y = torch.empty_like(a)
+    L.check(L.lib().dfw_silu(a.data_ptr(), _p(dy), y.data_ptr(), a.numel(), _dt(a), _stream()), "dfw_silu")
+    return y
 
 
 def sumsq(x):

@@ -1,0 +1,599 @@
+"""Training step of the two-input UNet on the MI355X engine (BASELINE configs[4]).
+
+Counterpart of the hot loop of
+/root/reference/train_tools/train_icl_multitask_nocrop_nearest_nshot_v3.py (= T):
+    T:1374  unet(z_refcat, t, ehs_nshot, is_target=False)    support pass, WITH grad: the K/V banks keep the graph
+    T:1375  unet(z_tag, t, ehs, is_target=True)              query pass over [own ; bank] (A:251-267)
+    T:1384  loss = F.mse_loss(pred.float(), target.float())  target = -z_mask_tag (T:1371)
+    T:1391  backward   T:1393 clip_grad_norm_(1.0)   T:1394 AdamW step (T:1186-1194)
+as ONE lock-step trunk pass over the batch [support images ; query images] (same arithmetic per image as the two
+passes, see unet.forward_pair), a hand-written backward through the same graph, and a fused AdamW on flat fp32
+buffers.  All compute is libdiffews_hip.so (ops.py / ops_bwd.py); torch is device memory, streams and -- once per
+optimizer step -- the re-layout of the 16-bit weight copies the data-gradient GEMMs read (transposes / tap mirrors).
+
+Parameters live in ONE flat fp32 master buffer in the engine's PACKED layouts (conv [Cout][ky][kx][Cin], fused
+[Wq;Wk;Wv], fused prompt [Wk2;Wv2] of all layers, the 22 time_emb_proj layers as one matrix, GEGLU rows interleaved),
+so weight gradients are produced directly in place by the TN GEMM and the optimizer is layout-agnostic;
+`state_dict()` / `grad_dict()` convert to the diffusers key layout (checkpoint format, T:1130-1140; parity tests).
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops, packing, weights
+from . import ops_bwd as ob
+
+
+class _Tape:
+    """Reverse-mode tape over engine tensors: ops register (output, closure).  Gradients are keyed by the tensor's
+    MEMORY (data pointer + element count), so a reshaped view handed to the next op routes its gradient to the op that
+    produced the storage; a tensor consumed more than once (residuals, skips, banks) has its gradients summed by the
+    library's add kernel; a closure receives the gradient in the shape of the output it was registered with."""
+
+    def __init__(self):
+        self.ops, self.g = [], {}
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), t.numel())
+
+    def add(self, out, fn):
+        self.ops.append((out, fn))
+
+    def accum(self, t, g):
+        k = self._key(t)
+        have = self.g.get(k)
+        self.g[k] = g if have is None else ob.add(have, g.reshape(have.shape))
+
+    def backward(self, out, dout):
+        self.accum(out, dout)
+        for o, fn in reversed(self.ops):
+            g = self.g.pop(self._key(o), None)
+            if g is not None:
+                fn(g.reshape(o.shape))
+        self.ops, self.g = [], {}
+
+
+class ParamStore:
+    """Flat fp32 master / gradient buffers + a 16-bit shadow, addressed by packed-parameter name."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = torch.device(device), dtype
+        self.spec, self._init, self.numel = {}, [], 0
+
+    def add(self, name, tensor):
+        t = tensor.detach().float().contiguous()
+        n = (t.numel() + 63) // 64 * 64              # 256-byte aligned entries
+        self.spec[name] = (self.numel, tuple(t.shape))
+        self._init.append((self.numel, t))
+        self.numel += n
+
+    def finalize(self):
+        self.master = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        for off, t in self._init:
+            self.master[off:off + t.numel()].copy_(t.reshape(-1))
+        self._init = None
+        self.grad = torch.zeros_like(self.master)
+        self.exp_avg = torch.zeros_like(self.master)
+        self.exp_avg_sq = torch.zeros_like(self.master)
+        self.shadow = self.master.to(self.dtype)
+        self.version = 0
+
+    def _view(self, buf, name):
+        off, shape = self.spec[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+    def p(self, name):      # fp32 master view (biases, norm parameters, boundary-conv weights are read as fp32)
+        return self._view(self.master, name)
+
+    def w(self, name):      # storage-dtype shadow view (MFMA operands)
+        return self._view(self.shadow, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def sync_shadow(self):
+        self.shadow.copy_(self.master)
+        self.version += 1
+
+
+class UNetTrainer:
+    """fwd + bwd (+ optimizer) of MyUNet2DConditionModel in training mode.  Boundary surface the launcher touches
+    (T:1105, 1136, 1163, 1189, 1376-1379): train(), parameters(), enable_gradient_checkpointing(),
+    clear_attn_bank(), save_pretrained(), state_dict()."""
+
+    def __init__(self, config, state_dict, torch_dtype=torch.bfloat16, device="cuda", loss_scale=1.0):
+        cfg = weights.default_unet_config()
+        cfg.update(config or {})
+        self.config = cfg
+        self.dtype, self.device = torch_dtype, torch.device(device)
+        L.lib()
+        weights.check_state_dict(state_dict, weights.unet_param_shapes(cfg), "unet")
+        self.loss_scale = float(loss_scale)
+        self.training = True
+        self.step_count = 0
+        self._derived, self._derived_version = {}, -1
+        self._build(state_dict)
+
+    # ------------------------------------------------------------------ parameters
+    def _resnet_prefixes(self):
+        cfg = self.config
+        lpb, nb = cfg["layers_per_block"], len(cfg["block_out_channels"])
+        out = [f"down_blocks.{i}.resnets.{j}." for i in range(nb) for j in range(lpb)]
+        out += ["mid_block.resnets.0.", "mid_block.resnets.1."]
+        out += [f"up_blocks.{i}.resnets.{j}." for i in range(nb) for j in range(lpb + 1)]
+        return out
+
+    def _transformer_prefixes(self):
+        cfg = self.config
+        lpb = cfg["layers_per_block"]
+        out = []
+        for i, typ in enumerate(cfg["down_block_types"]):
+            if typ == "CrossAttnDownBlock2D":
+                out += [f"down_blocks.{i}.attentions.{j}." for j in range(lpb)]
+        for i, typ in enumerate(cfg["up_block_types"]):
+            if typ == "CrossAttnUpBlock2D":
+                out += [f"up_blocks.{i}.attentions.{j}." for j in range(lpb + 1)]
+        out.append("mid_block.attentions.0.")
+        return out
+
+    def _build(self, sd):
+        cfg = self.config
+        P = ParamStore(self.device, self.dtype)
+        self.P = P
+        f = lambda k: sd[k].float()
+        P.add("conv_in.weight", packing.pack_conv_small(sd["conv_in.weight"]))
+        P.add("conv_in.bias", f("conv_in.bias"))
+        P.add("conv_in_ref.weight", packing.pack_conv_small(sd["conv_in_ref.weight"]))
+        P.add("conv_in_ref.bias", f("conv_in_ref.bias"))
+        for n in ("linear_1", "linear_2"):
+            P.add(f"time_embedding.{n}.weight", f(f"time_embedding.{n}.weight"))
+            P.add(f"time_embedding.{n}.bias", f(f"time_embedding.{n}.bias"))
+        rp = self._resnet_prefixes()
+        P.add("tp_w", torch.cat([f(p + "time_emb_proj.weight") for p in rp], 0))
+        P.add("tp_b", torch.cat([f(p + "time_emb_proj.bias") for p in rp], 0))
+        self.res = {}
+        off = 0
+        for p in rp:
+            cout, cin = sd[p + "conv1.weight"].shape[:2]
+            self.res[p] = dict(cin=cin, cout=cout, tslice=(off, cout), short=p + "conv_shortcut.weight" in sd)
+            off += cout
+            for n in ("norm1", "norm2"):
+                P.add(p + n + ".weight", f(p + n + ".weight"))
+                P.add(p + n + ".bias", f(p + n + ".bias"))
+            for n in ("conv1", "conv2"):
+                P.add(p + n + ".weight", packing.pack_conv3x3(f(p + n + ".weight")))
+                P.add(p + n + ".bias", f(p + n + ".bias"))
+            if self.res[p]["short"]:
+                P.add(p + "conv_shortcut.weight", packing.pack_conv1x1(f(p + "conv_shortcut.weight")))
+                P.add(p + "conv_shortcut.bias", f(p + "conv_shortcut.bias"))
+        self.tp_total = off
+        tp = self._transformer_prefixes()
+        heads = cfg["attention_head_dim"]
+        boc = list(cfg["block_out_channels"])
+        heads = [heads] * len(boc) if isinstance(heads, int) else list(heads)
+        self.tr = {}
+        kv, koff = [], 0
+        for p in tp:
+            b = p + "transformer_blocks.0."
+            C = sd[p + "proj_in.weight"].shape[0]
+            self.tr[p] = dict(C=C, heads=C // 64, kvslice=(koff, 2 * C))
+            koff += 2 * C
+            kv.append(torch.cat([f(b + "attn2.to_k.weight"), f(b + "attn2.to_v.weight")], 0))
+            P.add(p + "norm.weight", f(p + "norm.weight")); P.add(p + "norm.bias", f(p + "norm.bias"))
+            P.add(p + "proj_in.weight", f(p + "proj_in.weight")); P.add(p + "proj_in.bias", f(p + "proj_in.bias"))
+            for n in ("norm1", "norm2", "norm3"):
+                P.add(b + n + ".weight", f(b + n + ".weight")); P.add(b + n + ".bias", f(b + n + ".bias"))
+            P.add(b + "attn1.qkv", torch.cat([f(b + "attn1.to_q.weight"), f(b + "attn1.to_k.weight"), f(b + "attn1.to_v.weight")], 0))
+            P.add(b + "attn1.to_out.0.weight", f(b + "attn1.to_out.0.weight")); P.add(b + "attn1.to_out.0.bias", f(b + "attn1.to_out.0.bias"))
+            P.add(b + "attn2.to_q.weight", f(b + "attn2.to_q.weight"))
+            P.add(b + "attn2.to_out.0.weight", f(b + "attn2.to_out.0.weight")); P.add(b + "attn2.to_out.0.bias", f(b + "attn2.to_out.0.bias"))
+            wp, bp = packing.pack_geglu(f(b + "ff.net.0.proj.weight"), f(b + "ff.net.0.proj.bias"))
+            P.add(b + "ff1.weight", wp); P.add(b + "ff1.bias", bp)
+            P.add(b + "ff.net.2.weight", f(b + "ff.net.2.weight")); P.add(b + "ff.net.2.bias", f(b + "ff.net.2.bias"))
+            P.add(p + "proj_out.weight", f(p + "proj_out.weight")); P.add(p + "proj_out.bias", f(p + "proj_out.bias"))
+        self.kv_total = koff
+        P.add("kv_w_all", torch.cat(kv, 0))
+        self.samplers = []
+        for i in range(len(boc)):
+            for kind, name in (("down", f"down_blocks.{i}.downsamplers.0.conv."), ("up", f"up_blocks.{i}.upsamplers.0.conv.")):
+                if name + "weight" in sd:
+                    P.add(name + "weight", packing.pack_conv3x3(f(name + "weight")))
+                    P.add(name + "bias", f(name + "bias"))
+                    self.samplers.append(name)
+        P.add("conv_norm_out.weight", f("conv_norm_out.weight")); P.add("conv_norm_out.bias", f("conv_norm_out.bias"))
+        # conv_out: 4 output channels padded to 8 rows (rows 4..7 stay zero: zero weights, zero gradients), so the
+        # weight gradient of the padded output gradient lands in place
+        wo = packing.pack_conv3x3(f("conv_out.weight"))
+        P.add("conv_out.weight", torch.cat([wo, torch.zeros(8 - wo.shape[0], wo.shape[1])], 0))
+        P.add("conv_out.bias", torch.cat([f("conv_out.bias"), torch.zeros(8 - wo.shape[0])], 0))
+        P.finalize()
+        self.groups, self.eps = cfg["norm_num_groups"], cfg["norm_eps"]
+        self.heads_by_level = heads
+
+    # ------------------------------------------------------------------ boundary surface of the training launcher
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def requires_grad_(self, flag=True):
+        return self
+
+    def enable_gradient_checkpointing(self):
+        """T:1163.  Not needed on 288 GB: the forward keeps its 16-bit activations (~2 GB for a 7-shot episode)."""
+        return None
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None
+
+    def clear_attn_bank(self):
+        """T:1376-1379: the lock-step pass holds no bank state between calls."""
+        return None
+
+    @property
+    def module(self):       # `unet.module.clear_attn_bank()` under DDP (T:1377)
+        return self
+
+    def parameters(self):
+        """The flat fp32 master buffer (one tensor): what the optimizer and the gradient all-reduce operate on."""
+        return [self.P.master]
+
+    def export(self, flat):
+        """flat packed buffer (master or grad) -> dict in the diffusers key layout."""
+        P, out = self.P, {}
+        v = lambda name: P._view(flat, name)
+        out["conv_in.weight"] = v("conv_in.weight").reshape(-1, 3, 3, self.config["in_channels"]).permute(0, 3, 1, 2).contiguous()
+        out["conv_in.bias"] = v("conv_in.bias").clone()
+        out["conv_in_ref.weight"] = v("conv_in_ref.weight").reshape(-1, 3, 3, self.config["in_channels_ref"]).permute(0, 3, 1, 2).contiguous()
+        out["conv_in_ref.bias"] = v("conv_in_ref.bias").clone()
+        for n in ("linear_1", "linear_2"):
+            out[f"time_embedding.{n}.weight"] = v(f"time_embedding.{n}.weight").clone()
+            out[f"time_embedding.{n}.bias"] = v(f"time_embedding.{n}.bias").clone()
+        tpw, tpb = v("tp_w"), v("tp_b")
+        for p, r in self.res.items():
+            o, c = r["tslice"]
+            out[p + "time_emb_proj.weight"], out[p + "time_emb_proj.bias"] = tpw[o:o + c].clone(), tpb[o:o + c].clone()
+            for n in ("norm1", "norm2"):
+                out[p + n + ".weight"], out[p + n + ".bias"] = v(p + n + ".weight").clone(), v(p + n + ".bias").clone()
+            for n in ("conv1", "conv2"):
+                w = v(p + n + ".weight")
+                out[p + n + ".weight"] = packing.unpack_conv3x3_grad(w.view(w.shape[0], 9, -1))
+                out[p + n + ".bias"] = v(p + n + ".bias").clone()
+            if r["short"]:
+                w = v(p + "conv_shortcut.weight")
+                out[p + "conv_shortcut.weight"] = w.reshape(w.shape[0], w.shape[1], 1, 1).clone()
+                out[p + "conv_shortcut.bias"] = v(p + "conv_shortcut.bias").clone()
+        kvw = v("kv_w_all")
+        for p, t in self.tr.items():
+            b, C = p + "transformer_blocks.0.", t["C"]
+            for n in ("norm.weight", "norm.bias", "proj_in.weight", "proj_in.bias", "proj_out.weight", "proj_out.bias"):
+                out[p + n] = v(p + n).clone()
+            for n in ("norm1", "norm2", "norm3"):
+                out[b + n + ".weight"], out[b + n + ".bias"] = v(b + n + ".weight").clone(), v(b + n + ".bias").clone()
+            qkv = v(b + "attn1.qkv")
+            out[b + "attn1.to_q.weight"], out[b + "attn1.to_k.weight"], out[b + "attn1.to_v.weight"] = (qkv[i * C:(i + 1) * C].clone() for i in range(3))
+            for n in ("attn1.to_out.0.weight", "attn1.to_out.0.bias", "attn2.to_q.weight", "attn2.to_out.0.weight", "attn2.to_out.0.bias",
+                      "ff.net.2.weight", "ff.net.2.bias"):
+                out[b + n] = v(b + n).clone()
+            o, _ = t["kvslice"]
+            out[b + "attn2.to_k.weight"], out[b + "attn2.to_v.weight"] = kvw[o:o + C].clone(), kvw[o + C:o + 2 * C].clone()
+            w1, b1 = v(b + "ff1.weight"), v(b + "ff1.bias")
+            inv = torch.argsort(packing.geglu_perm(w1.shape[0] // 2)).to(w1.device)
+            out[b + "ff.net.0.proj.weight"], out[b + "ff.net.0.proj.bias"] = w1[inv].contiguous(), b1[inv].contiguous()
+        for name in self.samplers:
+            w = v(name + "weight")
+            out[name + "weight"] = packing.unpack_conv3x3_grad(w.view(w.shape[0], 9, -1))
+            out[name + "bias"] = v(name + "bias").clone()
+        out["conv_norm_out.weight"], out["conv_norm_out.bias"] = v("conv_norm_out.weight").clone(), v("conv_norm_out.bias").clone()
+        oc = self.config["out_channels"]
+        w = v("conv_out.weight")[:oc]
+        out["conv_out.weight"] = packing.unpack_conv3x3_grad(w.reshape(oc, 9, -1))
+        out["conv_out.bias"] = v("conv_out.bias")[:oc].clone()
+        return out
+
+    def state_dict(self):
+        return self.export(self.P.master)
+
+    def grad_dict(self):
+        return self.export(self.P.grad)
+
+    def save_pretrained(self, path, subfolder=None):
+        weights.save_pretrained(path, dict(self.config), {k: v.cpu() for k, v in self.state_dict().items()}, subfolder)
+
+    # ------------------------------------------------------------------ derived weight layouts (once per step)
+    def _d(self, kind, name):
+        """16-bit copies the data-gradient GEMMs read: 'T' = W^T of a Linear ([K, N] as the forward kernel's [N'][K']),
+        'D' = tap-mirrored, channel-swapped conv3x3 weight.  Rebuilt lazily after every optimizer step."""
+        if self._derived_version != self.P.version:
+            self._derived, self._derived_version = {}, self.P.version
+        key = (kind, name)
+        if key not in self._derived:
+            w = self.P.w(name)
+            if kind == "T":
+                self._derived[key] = w.t().contiguous()
+            else:
+                co = w.shape[0]
+                self._derived[key] = w.view(co, 9, -1).flip(1).permute(2, 1, 0).reshape(-1, 9 * co).contiguous()
+        return self._derived[key]
+
+    # ------------------------------------------------------------------ ops with registered backward
+    def _linear(self, tape, x, wname, bname=None, residual=None, colscale=None, need_dx=True):
+        P, gs = self.P, 1.0 / self.loss_scale
+        y = ops.linear(x, P.w(wname), bias=P.p(bname) if bname else None, residual=residual, colscale=colscale)
+
+        def bwd(dy):
+            N, K = P.spec[wname][1]
+            ob.gemm_tn(dy, x, out=P.g(wname).view(1, N, 1, K), accumulate=True, scale=gs)
+            if bname:
+                ob.colsum(dy, out=P.g(bname).view(1, N), accumulate=True, scale=gs)
+            if need_dx:
+                tape.accum(x, ops.linear(dy, self._d("T", wname)))
+            if residual is not None:
+                tape.accum(residual, dy)
+        tape.add(y, bwd)
+        return y
+
+    def _conv(self, tape, x, wname, bname, stride=1, ups=False, rowbias=None, residual=None, dtproj=None, tslice=None,
+              need_dx=True):
+        P, gs = self.P, 1.0 / self.loss_scale
+        cout = P.spec[wname][1][0]
+        B, Hi, Wi, Cin = x.shape
+        y = ops.conv3x3(x, P.w(wname), cout, bias=P.p(bname), stride=stride, pad=1, ups=ups, rowbias=rowbias, residual=residual)
+        Ho, Wo = y.shape[1:3]
+
+        def bwd(dy):
+            ob.gemm_tn(dy, x, taps=9, geom=(Hi, Wi, Ho, Wo, stride, 1, int(ups)), out=P.g(wname).view(1, cout, 9, Cin),
+                       accumulate=True, scale=gs)
+            ob.colsum(dy, out=P.g(bname).view(1, cout), accumulate=True, scale=gs)
+            if tslice is not None:      # d(time_emb_proj output)[img] = sum over the image's pixels (kept at loss scale)
+                o, c = tslice
+                ob.colsum(dy, segs=B, out=dtproj[:, o:o + c])
+            if need_dx:
+                wd = self._d("D", wname)
+                if stride == 2:
+                    dx = ops.conv3x3(ob.zero_stuff2x(dy), wd, Cin)
+                elif ups:
+                    dx = ob.pool2x2_sum(ops.conv3x3(dy, wd, Cin))
+                else:
+                    dx = ops.conv3x3(dy, wd, Cin)
+                tape.accum(x, dx)
+            if residual is not None:
+                tape.accum(residual, dy)
+        tape.add(y, bwd)
+        return y
+
+    def _gn(self, tape, x, gname, bname, eps, silu):
+        P, gs = self.P, 1.0 / self.loss_scale
+        y, mr = ops.groupnorm(x, P.p(gname), P.p(bname), self.groups, eps, silu=silu, return_stats=True)
+
+        def bwd(dy):
+            tape.accum(x, ob.groupnorm_bwd(x, dy, mr, P.p(gname), P.p(bname), self.groups, silu, P.g(gname), P.g(bname),
+                                           accumulate=True, grad_scale=gs))
+        tape.add(y, bwd)
+        return y
+
+    def _ln(self, tape, x, gname, bname):
+        P, gs = self.P, 1.0 / self.loss_scale
+        y = ops.layernorm(x, P.p(gname), P.p(bname))
+
+        def bwd(dy):
+            tape.accum(x, ob.layernorm_bwd(x, dy, P.p(gname), P.g(gname), P.g(bname), accumulate=True, grad_scale=gs))
+        tape.add(y, bwd)
+        return y
+
+    def _resnet(self, tape, p, x, tproj, dtproj):
+        r = self.res[p]
+        B, H, W, Cin = x.shape
+        h = self._gn(tape, x, p + "norm1.weight", p + "norm1.bias", self.eps, True)
+        o, c = r["tslice"]
+        h = self._conv(tape, h, p + "conv1.weight", p + "conv1.bias", rowbias=tproj[:, o:o + c], dtproj=dtproj, tslice=r["tslice"])
+        h = self._gn(tape, h, p + "norm2.weight", p + "norm2.bias", self.eps, True)
+        sc = x
+        if r["short"]:
+            sc = self._linear(tape, x.view(-1, Cin), p + "conv_shortcut.weight", p + "conv_shortcut.bias").view(B, H, W, r["cout"])
+        return self._conv(tape, h, p + "conv2.weight", p + "conv2.bias", residual=sc)
+
+    def _transformer(self, tape, p, x, kv_all, dkv_all, L_ctx, n_ref):
+        P = self.P
+        t = self.tr[p]
+        B, H, W, C = x.shape
+        N, heads = H * W, t["heads"]
+        b = p + "transformer_blocks.0."
+        n = self._gn(tape, x, p + "norm.weight", p + "norm.bias", 1e-6, False)
+        t0 = self._linear(tape, n.view(-1, C), p + "proj_in.weight", p + "proj_in.bias")
+        l1 = self._ln(tape, t0, b + "norm1.weight", b + "norm1.bias")
+        qkv = self._linear(tape, l1, b + "attn1.qkv", colscale=(C, ops.FSA_QSCALE))
+        q3 = qkv.view(B, N, 3 * C)
+        q, k, v = q3[..., :C], q3[..., C:2 * C], q3[..., 2 * C:]
+        lse = torch.empty(B, heads, N, dtype=torch.float32, device=x.device)
+        nshot = n_ref // (B - n_ref) if n_ref else 0
+        if n_ref:
+            att = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=nshot, n_plain=n_ref, q_prescaled=True, lse=lse)
+        else:
+            att = ops.fsa_attention(q, k, v, heads, q_prescaled=True, lse=lse)
+
+        def att_bwd(datt):
+            tape.accum(qkv, ob.fsa_attention_bwd(q3, att, datt, lse, heads, nshot=nshot, n_plain=n_ref).view(-1, 3 * C))
+        tape.add(att, att_bwd)
+        t1 = self._linear(tape, att.view(-1, C), b + "attn1.to_out.0.weight", b + "attn1.to_out.0.bias", residual=t0)
+        l2 = self._ln(tape, t1, b + "norm2.weight", b + "norm2.bias")
+        q2 = self._linear(tape, l2, b + "attn2.to_q.weight")
+        o, _ = t["kvslice"]
+        kv2 = kv_all.view(B, L_ctx, -1)[..., o:o + 2 * C]
+        q2v = q2.view(B, N, C)
+        ca = ops.cross_attention(q2v, kv2[..., :C], kv2[..., C:], heads)
+
+        def ca_bwd(dca):
+            dkv = dkv_all.view(B, L_ctx, -1)[..., o:o + 2 * C]
+            tape.accum(q2, ob.cross_attention_bwd(q2v, kv2[..., :C], kv2[..., C:], dca, heads, dkv[..., :C], dkv[..., C:]).view(-1, C))
+        tape.add(ca, ca_bwd)
+        t2 = self._linear(tape, ca.view(-1, C), b + "attn2.to_out.0.weight", b + "attn2.to_out.0.bias", residual=t1)
+        l3 = self._ln(tape, t2, b + "norm3.weight", b + "norm3.bias")
+        pre = self._linear(tape, l3, b + "ff1.weight", b + "ff1.bias")
+        ff = ob.geglu_fwd(pre)
+        tape.add(ff, lambda dff: tape.accum(pre, ob.geglu_bwd(pre, dff)))
+        t3 = self._linear(tape, ff, b + "ff.net.2.weight", b + "ff.net.2.bias", residual=t2)
+        out = self._linear(tape, t3, p + "proj_out.weight", p + "proj_out.bias", residual=x.view(-1, C))
+        return out.view(B, H, W, C)
+
+    # ------------------------------------------------------------------ the step
+    def forward_backward(self, z_refcat, z_tag, target, timestep, ehs, zero_grad=True):
+        """One micro-step: lock-step forward over [support ; query] latents, MSE(pred, target), backward.
+        z_refcat [b*s, 8, h, w] (cat([z_ref, z_mask_ref], 1), T:1360-1362), z_tag [b, 4, h, w], target [b, 4, h, w]
+        (= -z_mask_tag, T:1371), all fp32 NCHW; ehs [1, L, D] or [b, L, D] prompt embedding (T:1368).
+        Returns (loss fp32 tensor [1], pred [b, 4, h, w] fp32).  Gradients accumulate into P.grad (fp32, packed)."""
+        P, dt, dev, cfg = self.P, self.dtype, self.device, self.config
+        tape = _Tape()
+        gs = 1.0 / self.loss_scale
+        if zero_grad:
+            P.grad.zero_()
+        zr = z_refcat.to(dev, torch.float32).contiguous()
+        zq = z_tag.to(dev, torch.float32).contiguous()
+        n_ref, bq = zr.shape[0], zq.shape[0]
+        Bt = n_ref + bq
+        c0 = cfg["block_out_channels"][0]
+        # ---- time embedding (U:991-1015) and the 22 fused time projections
+        t = torch.full((Bt,), float(timestep), dtype=torch.float32, device=dev)
+        temb = ops.timestep_embedding(t, c0, dt, cfg["flip_sin_to_cos"], float(cfg["freq_shift"]))
+        e1 = self._linear(tape, temb, "time_embedding.linear_1.weight", "time_embedding.linear_1.bias", need_dx=False)
+        a1 = ob.silu(e1)
+        tape.add(a1, lambda d: tape.accum(e1, ob.silu(e1, d)))
+        e2 = self._linear(tape, a1, "time_embedding.linear_2.weight", "time_embedding.linear_2.bias")
+        a2 = ob.silu(e2)
+        tape.add(a2, lambda d: tape.accum(e2, ob.silu(e2, d)))
+        tproj = ops.linear(a2, P.w("tp_w"), bias=P.p("tp_b"), out_f32=True)                  # [Bt, sum Cout] fp32
+        dtproj = torch.zeros(Bt, self.tp_total, dtype=torch.float32, device=dev)            # filled by the resnets' closures
+
+        def tproj_bwd(_):
+            # every resnet has written its column slice of dtproj by now (they sit later on the tape)
+            d16 = ob.nchw_to_nhwc(dtproj.view(Bt, self.tp_total, 1, 1), dt, cp=self.tp_total).view(Bt, self.tp_total)
+            ob.gemm_tn(d16, a2, out=P.g("tp_w").view(1, self.tp_total, 1, a2.shape[1]), accumulate=True, scale=gs)
+            ob.colsum(d16, out=P.g("tp_b").view(1, self.tp_total), accumulate=True, scale=gs)
+            tape.accum(a2, ops.linear(d16, self._d("T", "tp_w")))
+        tape.add(tproj, tproj_bwd)
+        # ---- prompt K/V of all layers in one GEMM
+        e = ehs.to(dev, dt)
+        if e.shape[0] == 1:
+            e = e.expand(Bt, -1, -1)
+        L_ctx = e.shape[1]
+        ehs2d = e.reshape(Bt * L_ctx, e.shape[2]).contiguous()
+        kv_all = ops.linear(ehs2d, P.w("kv_w_all"))
+        dkv_all = torch.zeros_like(kv_all)                                                   # filled by the attn2 closures
+        tape.add(kv_all, lambda _: ob.gemm_tn(dkv_all, ehs2d, out=P.g("kv_w_all").view(1, self.kv_total, 1, ehs2d.shape[1]),
+                                              accumulate=True, scale=gs))
+        # ---- conv_in_ref | conv_in (U:1117-1121)
+        h, w = zq.shape[2:]
+        x = torch.empty(Bt, h, w, c0, dtype=dt, device=dev)
+        if n_ref:
+            ops.conv_small(zr, P.p("conv_in_ref.weight"), P.p("conv_in_ref.bias"), c0, 9, dt, out=x[:n_ref])
+        ops.conv_small(zq, P.p("conv_in.weight"), P.p("conv_in.bias"), c0, 9, dt, out=x[n_ref:])
+
+        def conv_in_bwd(dx):
+            geom = (h, w, h, w, 1, 1, 0)
+            if n_ref:
+                zin = ob.nchw_to_nhwc(zr, dt, cp=8)
+                ob.gemm_tn(dx[:n_ref], zin, taps=9, geom=geom, out=P.g("conv_in_ref.weight").view(1, c0, 9, 8), accumulate=True, scale=gs)
+                ob.colsum(dx[:n_ref], out=P.g("conv_in_ref.bias").view(1, c0), accumulate=True, scale=gs)
+            zin = ob.nchw_to_nhwc(zq, dt, cp=8)
+            g8 = ob.gemm_tn(dx[n_ref:], zin, taps=9, geom=geom, scale=gs)                  # [1, c0, 9, 8]: 4 real input channels
+            P.g("conv_in.weight").add_(g8.view(c0, 9, 8)[..., :cfg["in_channels"]])
+            ob.colsum(dx[n_ref:], out=P.g("conv_in.bias").view(1, c0), accumulate=True, scale=gs)
+        tape.add(x, conv_in_bwd)
+        # ---- trunk (U:1153-1243)
+        lpb, nb = cfg["layers_per_block"], len(cfg["block_out_channels"])
+        skips = [x]
+        for i, typ in enumerate(cfg["down_block_types"]):
+            for j in range(lpb):
+                x = self._resnet(tape, f"down_blocks.{i}.resnets.{j}.", x, tproj, dtproj)
+                if typ == "CrossAttnDownBlock2D":
+                    x = self._transformer(tape, f"down_blocks.{i}.attentions.{j}.", x, kv_all, dkv_all, L_ctx, n_ref)
+                skips.append(x)
+            if i != nb - 1:
+                x = self._conv(tape, x, f"down_blocks.{i}.downsamplers.0.conv.weight", f"down_blocks.{i}.downsamplers.0.conv.bias", stride=2)
+                skips.append(x)
+        x = self._resnet(tape, "mid_block.resnets.0.", x, tproj, dtproj)
+        x = self._transformer(tape, "mid_block.attentions.0.", x, kv_all, dkv_all, L_ctx, n_ref)
+        x = self._resnet(tape, "mid_block.resnets.1.", x, tproj, dtproj)
+        for i, typ in enumerate(cfg["up_block_types"]):
+            for j in range(lpb + 1):
+                s = skips.pop()
+                cat = ops.concat_channels(x, s)
+                ca_, cs_ = x.shape[-1], s.shape[-1]
+
+                def cat_bwd(d, x=x, s=s, ca_=ca_, cs_=cs_):
+                    tape.accum(x, ob.slice_channels(d, 0, ca_))
+                    tape.accum(s, ob.slice_channels(d, ca_, cs_))
+                tape.add(cat, cat_bwd)
+                x = self._resnet(tape, f"up_blocks.{i}.resnets.{j}.", cat, tproj, dtproj)
+                if typ == "CrossAttnUpBlock2D":
+                    x = self._transformer(tape, f"up_blocks.{i}.attentions.{j}.", x, kv_all, dkv_all, L_ctx, n_ref)
+            if i != nb - 1:
+                x = self._conv(tape, x, f"up_blocks.{i}.upsamplers.0.conv.weight", f"up_blocks.{i}.upsamplers.0.conv.bias", ups=True)
+        # ---- out (U:1246-1249)
+        hn = self._gn(tape, x, "conv_norm_out.weight", "conv_norm_out.bias", self.eps, True)
+        oc = cfg["out_channels"]
+        pred_all = ops.conv3x3(hn, P.w("conv_out.weight")[:oc], oc, bias=P.p("conv_out.bias")[:oc], out_nchw_f32=True)
+        pred = pred_all[n_ref:]                                   # the support pass' output is discarded (T:1381)
+        # ---- loss (T:1384) and its gradient
+        tgt = target.to(dev, torch.float32).contiguous()
+        dpred = torch.zeros(Bt, h, w, 8, dtype=dt, device=dev)       # support rows: zero gradient (pred_ref * 0, T:1381)
+        dpn = torch.zeros(Bt, oc, h, w, dtype=torch.float32, device=dev)
+        loss, _ = ob.mse_loss(pred, tgt, dt, loss_scale=self.loss_scale, dpred_out=dpred[n_ref:], dpred_nchw_out=dpn[n_ref:])
+        # conv_out backward: weight / bias gradients in place (padded to 8 rows), data gradient by the direct conv
+        ob.gemm_tn(dpred, hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=True, scale=gs)
+        ob.colsum(dpred, out=P.g("conv_out.bias").view(1, 8), accumulate=True, scale=gs)
+        wdo = P.p("conv_out.weight")[:oc].view(oc, 9, c0).flip(1).permute(2, 1, 0).contiguous()     # [c0][tap'][oc] fp32
+        dhn = ops.conv_small(dpn, wdo, None, c0, 9, dt)
+        tape.accum(tproj, dtproj)        # seeds of the two conditioning paths: their buffers fill up during the walk
+        tape.accum(kv_all, dkv_all)
+        tape.backward(hn, dhn)
+        return loss, pred
+
+    # ------------------------------------------------------------------ optimizer (T:1186-1194, T:1217-1223, T:1393-1394)
+    def grad_sumsq(self):
+        return ob.sumsq(self.P.grad)
+
+    def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0):
+        """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers, then refresh the 16-bit shadow."""
+        P = self.P
+        self.step_count += 1
+        ss = ob.sumsq(P.grad) if max_grad_norm and max_grad_norm > 0 else None
+        ob.adamw(P.master, P.grad, P.exp_avg, P.exp_avg_sq, self.step_count, lr, betas, eps, weight_decay, grad_sumsq=ss,
+                 max_grad_norm=max_grad_norm or 0.0)
+        P.sync_shadow()
+        return ss
+
+
+def poly_lr(base_lr, step, total_steps, warmup_steps=0, lr_end=1e-7, power=1.0):
+    """diffusers get_scheduler("polynomial", power=1.0) (T:1217-1223): linear warm-up, then polynomial decay."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    if step > total_steps:
+        return lr_end
+    remaining = 1 - (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return (base_lr - lr_end) * remaining ** power + lr_end
+
+
+def allreduce_flat_gradient(flat_grad, world_size=None, bucket_elems=54_000_000, group=None):
+    """Gradient all-reduce of DDP (T:1226-1228, T:1391) on the flat fp32 gradient: SUM over ranks in fixed buckets
+    (216 MB each: eight cover the 866 M parameters), then the 1 / world_size average.  RCCL over xGMI on GPU tensors
+    (backend "nccl"), gloo on CPU tensors.  Bucket boundaries depend only on the buffer length, so every rank issues
+    the same sequence of collectives."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad
+    ws = world_size or dist.get_world_size(group)
+    if ws == 1:
+        return flat_grad
+    n = flat_grad.numel()
+    for s0 in range(0, n, bucket_elems):
+        dist.all_reduce(flat_grad[s0:min(n, s0 + bucket_elems)], op=dist.ReduceOp.SUM, group=group)
+    flat_grad.mul_(1.0 / ws)
+    return flat_grad

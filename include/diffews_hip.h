@@ -384,9 +384,10 @@ int dfw_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t HW, 
 
 /* loss = mean((pred - target)^2) (F.mse_loss, T:1384; pred/target NCHW fp32 [B][C][HW], C <= 8) and
  * dpred = 2 (pred - target) / numel * loss_scale as NHWC storage dtype [B][HW][8] (zero-initialised by the
- * caller: channels C..7 are not written).  workspace: 256 floats. */
-int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* loss, float* workspace, int32_t B, int32_t C,
-                 int32_t HW, float loss_scale, int32_t dtype, dfw_stream_t stream);
+ * caller: channels C..7 are not written); dpred_nchw (optional): the same rounded values as NCHW fp32 [B][C][HW], the
+ * input of conv_out's data-gradient conv.  workspace: 256 floats. */
+int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* dpred_nchw, float* loss, float* workspace,
+                 int32_t B, int32_t C, int32_t HW, float loss_scale, int32_t dtype, dfw_stream_t stream);
 
 /* KV-fusion attention backward for the lock-step batch (dfw_fsa_args.n_plain form; nshot == 0: plain
  * self-attention).  qkv [batch][n][ld >= 3C]: the fused projection output with q PRE-SCALED
@@ -402,6 +403,25 @@ typedef struct {
 } dfw_fsa_bwd_args;
 
 int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream);
+
+/* Cross-attention (attn2) backward over a short context; same tensor conventions as dfw_cross_attention.
+ * dq [batch][n_q][heads*64] (strides lddq / dq_bs); dk / dv [batch][L][heads*64] at row stride lddkv, image stride
+ * dkv_bs (column slices of the fused prompt K/V gradient buffer).  workspace: dfw_cross_attention_bwd_workspace_bytes. */
+typedef struct {
+  const void* q; const void* k; const void* v; const void* dout; void* dq; void* dk; void* dv;
+  void* workspace; size_t workspace_bytes;
+  int32_t batch, heads, n_q, L;
+  int32_t ldq, ldk, ldv, ldo, lddq, lddkv;
+  int64_t q_bs, k_bs, v_bs, o_bs, dq_bs, dkv_bs;
+  float scale;
+  int32_t dtype;
+} dfw_xattn_bwd_args;
+
+int dfw_cross_attention_bwd(const dfw_xattn_bwd_args* a, dfw_stream_t stream);
+size_t dfw_cross_attention_bwd_workspace_bytes(int32_t batch, int32_t heads, int32_t n_q, int32_t L);
+
+/* y = silu(a) (dy == NULL) or y = dy * silu'(a), n storage-dtype elements (the timestep-embedding MLP). */
+int dfw_silu(const void* a, const void* dy, void* y, int64_t n, int32_t dtype, dfw_stream_t stream);
 
 /* Sum of squares of an fp32 vector (the global gradient norm of clip_grad_norm_, T:1393); workspace: 1024 floats. */
 int dfw_sumsq(const float* x, float* out, float* workspace, int64_t n, dfw_stream_t stream);

@@ -241,3 +241,95 @@ def test_fsa_attention_backward(B, dtype, b, nshot, heads, N):
     assert rel(dqkv[..., C:2 * C], dref[..., C:2 * C]) < 2 * TOL[dtype], "dk"
     assert rel(dqkv[..., 2 * C:], dref[..., 2 * C:]) < 2 * TOL[dtype], "dv"
     assert rel(dqkv[..., :C], want_q) < 2 * TOL[dtype], "dq"
+
+
+# ------------------------------------------------------------------------------------------------ whole step
+def _train_setup(dtype, b, nshot, seed=0):
+    from diffews_amd import config, weights
+    from oracle.unet import OracleUNet
+    ucfg = config.get("tiny_unet")
+    kw = {k: v for k, v in ucfg.items() if not k.startswith("_")}
+    usd = weights.synthetic_unet_state_dict(ucfg, round_to=dtype)
+    ou = OracleUNet(**kw)
+    ou.load_state_dict(usd)
+    ou.train()
+    g = torch.Generator().manual_seed(seed)
+    h = 16
+    z_refcat = torch.randn(b * nshot, 8, h, h, generator=g) * 0.5
+    z_tag = torch.randn(b, 4, h, h, generator=g) * 0.5
+    target = torch.randn(b, 4, h, h, generator=g) * 0.5
+    ehs = (torch.randn(1, 77, ucfg["cross_attention_dim"], generator=g)).to(dtype).float()   # 77-token prompt (T:1368)
+    return ucfg, usd, ou, z_refcat, z_tag, target, ehs
+
+
+def _oracle_step(ou, z_refcat, z_tag, target, ehs, b, nshot):
+    """T:1374-1384 on the oracle with autograd: support pass fills the banks (graph kept), query pass reads them."""
+    ou.zero_grad()
+    ou.clear_attn_bank()
+    ou(z_refcat, 1, ehs.repeat(b * nshot, 1, 1), is_target=False)
+    pred = ou(z_tag, 1, ehs.repeat(b, 1, 1), is_target=True)
+    ou.clear_attn_bank()
+    loss = F.mse_loss(pred.float(), target.float())
+    loss.backward()
+    return float(loss), pred.detach(), {k: p.grad.detach().clone() for k, p in ou.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype,b,nshot", [(torch.bfloat16, 1, 1), (torch.bfloat16, 1, 2), (torch.bfloat16, 2, 1),
+                                           (torch.float16, 1, 2)])
+def test_training_step_gradients_vs_oracle_autograd(hip_lib, dtype, b, nshot):
+    """Whole training micro-step on the tiny UNet: lock-step forward, MSE(pred, -z_mask_tag), hand-written backward ==
+    torch autograd of the oracle's two-pass graph (banks with grad), for every parameter of the diffusers layout:
+    the support pass' conv_in_ref, all 16 transformer blocks (self-attention dk / dv through the bank), resnets, time
+    MLP + the fused time projections, the prompt K / V projections, samplers, conv_out.  fp16 runs with a loss scale."""
+    from diffews_amd.train import UNetTrainer
+    ucfg, usd, ou, z_refcat, z_tag, target, ehs = _train_setup(dtype, b, nshot)
+    loss_ref, pred_ref, gref = _oracle_step(ou, z_refcat, z_tag, target, ehs, b, nshot)
+    tr = UNetTrainer(ucfg, usd, torch_dtype=dtype, loss_scale=1.0 if dtype == torch.bfloat16 else 1024.0)
+    assert set(tr.state_dict()) == set(usd) and all(torch.equal(tr.state_dict()[k].cpu(), usd[k].float()) for k in usd)
+    loss, pred = tr.forward_backward(z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda())
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    assert rel(pred, pred_ref) < tol
+    assert abs(float(loss) - loss_ref) < 3 * tol * loss_ref
+    g = tr.grad_dict()
+    assert set(g) == set(gref), set(gref) ^ set(g)
+    # every tensor close in relative L2 (bf16 activations / activation gradients: a few % per tensor), the flat
+    # gradient as a whole much closer in direction
+    gtol = 0.12 if dtype == torch.bfloat16 else 0.03
+    worst = max(((rel(g[k], gref[k]), k) for k in gref), key=lambda t: t[0])
+    assert worst[0] < gtol, worst
+    flat = torch.cat([g[k].float().cpu().reshape(-1) for k in sorted(gref)])
+    flat_ref = torch.cat([gref[k].reshape(-1) for k in sorted(gref)])
+    cos = float(F.cosine_similarity(flat, flat_ref, dim=0))
+    assert cos > (0.998 if dtype == torch.bfloat16 else 0.9999), cos
+    assert rel(flat, flat_ref) < (0.06 if dtype == torch.bfloat16 else 0.012)
+    # a second call accumulates (gradient accumulation, T:1323) when zero_grad=False
+    tr.forward_backward(z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda(), zero_grad=False)
+    g2 = tr.grad_dict()
+    assert rel(g2["conv_out.weight"], 2 * g["conv_out.weight"]) < 1e-5
+
+
+def test_training_loop_loss_decreases_and_matches_torch_adamw(hip_lib):
+    """Five optimizer steps (clip 1.0 + AdamW + poly LR) on one tiny episode: the loss falls, and the trajectory
+    follows the oracle trained by torch.optim.AdamW on the same data (bf16 forward/backward vs fp32: loose)."""
+    from diffews_amd.train import UNetTrainer, poly_lr
+    dtype, b, nshot = torch.bfloat16, 1, 1
+    ucfg, usd, ou, z_refcat, z_tag, target, ehs = _train_setup(dtype, b, nshot, seed=3)
+    tr = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    tr.train()
+    assert tr.module is tr and len(tr.parameters()) == 1 and tr.enable_gradient_checkpointing() is None
+    opt = torch.optim.AdamW(ou.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    ours, theirs = [], []
+    for step in range(5):
+        lr = poly_lr(1e-4, step, 100)
+        loss, _ = tr.forward_backward(z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda())
+        tr.optimizer_step(lr, max_grad_norm=1.0)
+        ours.append(float(loss))
+        for gparam in opt.param_groups:
+            gparam["lr"] = lr
+        l, _, _ = _oracle_step(ou, z_refcat, z_tag, target, ehs, b, nshot)
+        torch.nn.utils.clip_grad_norm_(ou.parameters(), 1.0)
+        opt.step()
+        theirs.append(l)
+    assert ours[-1] < ours[0] and theirs[-1] < theirs[0]
+    assert all(abs(a - c) < 0.05 * c for a, c in zip(ours, theirs)), (ours, theirs)
+    assert poly_lr(1e-4, 100, 100) == pytest.approx(1e-7) and poly_lr(1e-4, 5, 100, warmup_steps=10) == pytest.approx(5e-5)

@@ -44,7 +44,10 @@ def test_struct_layouts_match_header():
     hdr = open(os.path.join(ROOT, "include", "diffews_hip.h")).read()
     for cname, cls in (("dfw_gemm_args", _lib.GemmArgs), ("dfw_fsa_args", _lib.FsaArgs), ("dfw_xattn_args", _lib.XattnArgs),
                        ("dfw_groupnorm_args", _lib.GroupNormArgs), ("dfw_layernorm_args", _lib.LayerNormArgs),
-                       ("dfw_conv_small_args", _lib.ConvSmallArgs)):
+                       ("dfw_conv_small_args", _lib.ConvSmallArgs), ("dfw_gemm_tn_args", _lib.GemmTnArgs),
+                       ("dfw_groupnorm_bwd_args", _lib.GroupNormBwdArgs), ("dfw_layernorm_bwd_args", _lib.LayerNormBwdArgs),
+                       ("dfw_fsa_bwd_args", _lib.FsaBwdArgs), ("dfw_xattn_bwd_args", _lib.XattnBwdArgs),
+                       ("dfw_adamw_args", _lib.AdamWArgs), ("dfw_image_args", _lib.ImageArgs)):
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", hdr).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -60,14 +63,18 @@ def test_struct_layouts_match_header():
 def test_sizeof_structs_against_compiler(tmp_path):
     from diffews_amd import _lib
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "diffews_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
-                   'sizeof(dfw_gemm_args),sizeof(dfw_fsa_args),sizeof(dfw_xattn_args),sizeof(dfw_groupnorm_args),'
-                   'sizeof(dfw_layernorm_args),sizeof(dfw_conv_small_args));return 0;}\n')
+    names = ["dfw_gemm_args", "dfw_fsa_args", "dfw_xattn_args", "dfw_groupnorm_args", "dfw_layernorm_args",
+             "dfw_conv_small_args", "dfw_gemm_tn_args", "dfw_groupnorm_bwd_args", "dfw_layernorm_bwd_args",
+             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_adamw_args", "dfw_image_args"]
+    src.write_text('#include <stdio.h>\n#include "diffews_hip.h"\nint main(){' +
+                   "".join(f'printf("%zu ", sizeof({n}));' for n in names) + 'return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.FsaArgs, _lib.XattnArgs, _lib.GroupNormArgs,
-                                                _lib.LayerNormArgs, _lib.ConvSmallArgs)]
+                                                _lib.LayerNormArgs, _lib.ConvSmallArgs, _lib.GemmTnArgs,
+                                                _lib.GroupNormBwdArgs, _lib.LayerNormBwdArgs, _lib.FsaBwdArgs,
+                                                _lib.XattnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs)]
 
 
 def test_product_never_imports_oracle():
@@ -274,3 +281,43 @@ def test_bench_refuses_to_report_fewer_gpus_than_asked():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+_GRAD_WORKER = r'''
+import os, sys, hashlib, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from diffews_amd.train import allreduce_flat_gradient
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n = 1_000_003                                            # not a multiple of the bucket size: ragged last bucket
+g = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank)) * 10.0 ** torch.randint(-6, 3, (n,), generator=torch.Generator().manual_seed(7)).float()
+allreduce_flat_gradient(g, bucket_elems=65_536)
+if rank == 0:
+    print("SHA", hashlib.sha256(g.numpy().tobytes()).hexdigest())
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_bucketed_gradient_all_reduce_is_bit_exact(tmp_path):
+    """The training step's one collective (DDP's gradient all-reduce, T:1226-1228 / T:1391) rehearsed on CPU: the
+    flat fp32 gradient summed over 2 gloo ranks in fixed buckets, then averaged == the single-process mean of the two
+    micro-batch gradients, bit for bit (a + b is commutative in IEEE fp32, * 0.5 is exact)."""
+    import hashlib
+    script = tmp_path / "gw.py"
+    script.write_text(_GRAD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29573", str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
+    sha = [l.split()[1] for l in out.splitlines() if l.startswith("SHA")][-1]
+    n = 1_000_003
+    sc = 10.0 ** torch.randint(-6, 3, (n,), generator=torch.Generator().manual_seed(7)).float()
+    g0 = torch.randn(n, generator=torch.Generator().manual_seed(100)) * sc
+    g1 = torch.randn(n, generator=torch.Generator().manual_seed(101)) * sc
+    want = (g0 + g1) * 0.5
+    assert hashlib.sha256(want.numpy().tobytes()).hexdigest() == sha
+    # single process / uninitialised process group: a no-op, not an error
+    from diffews_amd.train import allreduce_flat_gradient, poly_lr
+    g = g0.clone()
+    assert allreduce_flat_gradient(g) is g and torch.equal(g, g0)
+    assert poly_lr(1e-4, 0, 10) == pytest.approx(1e-4) and poly_lr(1e-4, 10, 10) == pytest.approx(1e-7)
