@@ -388,60 +388,88 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const XabP p) {
     for (int i = 0; i < 8; ++i) { Qs[r * 65 + c8 * 8 + i] = fq[i]; Ds[r * 65 + c8 * 8 + i] = fd[i]; }
   }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int r = threadIdx.x, row = chunk * 64 + r;
+  {
+    // phase 1: 4 threads per query row, each owning 16 of the 64 head dims: dot products are 16 FMAs + two lane
+    // exchanges (the 4 threads are adjacent lanes), dq needs no exchange at all
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3, d0 = part * 16, row = chunk * 64 + r;
+    const bool rok = row < p.n_q;
+    float qv[16], dv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { qv[i] = Qs[r * 65 + d0 + i]; dv[i] = Ds[r * 65 + d0 + i]; }
     float m = -1e30f;
     for (int j = 0; j < L; ++j) {
       float sd = 0.f;
 #pragma unroll
-      for (int i = 0; i < 64; ++i) sd += Qs[r * 65 + i] * Ks[j * 64 + i];
+      for (int i = 0; i < 16; ++i) sd += qv[i] * Ks[j * 64 + d0 + i];
+      sd += __shfl_xor(sd, 1, 64);
+      sd += __shfl_xor(sd, 2, 64);
       sd *= p.scale;
-      Ps[r * LP + j] = sd;
+      if (part == 0) Ps[r * LP + j] = sd;
       m = fmaxf(m, sd);
     }
     float l = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const float e = __expf(Ps[r * LP + j] - m);
-      Ps[r * LP + j] = e;
-      l += e;
-    }
+    for (int j = 0; j < L; ++j) l += __expf(Ps[r * LP + j] - m);     // every part reads the row written by part 0 (same wave)
     const float inv = 1.0f / l;
     float delta = 0.f;
     for (int j = 0; j < L; ++j) {
       float dp = 0.f;
 #pragma unroll
-      for (int i = 0; i < 64; ++i) dp += Ds[r * 65 + i] * Vs[j * 64 + i];
-      const float pr = Ps[r * LP + j] * inv;
-      Ps[r * LP + j] = row < p.n_q ? pr : 0.f;
-      Ss[r * LP + j] = dp;
+      for (int i = 0; i < 16; ++i) dp += dv[i] * Vs[j * 64 + d0 + i];
+      dp += __shfl_xor(dp, 1, 64);
+      dp += __shfl_xor(dp, 2, 64);
+      const float pr = __expf(Ps[r * LP + j] - m) * inv;
+      if (part == 0) Ss[r * LP + j] = dp;
       delta += pr * dp;
     }
-    float dq[64];
+    float dq[16];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) dq[i] = 0.f;
+    for (int i = 0; i < 16; ++i) dq[i] = 0.f;
     for (int j = 0; j < L; ++j) {
-      const float ds = row < p.n_q ? Ps[r * LP + j] * (Ss[r * LP + j] - delta) * p.scale : 0.f;
-      Ss[r * LP + j] = ds;
+      const float pr = rok ? __expf(Ps[r * LP + j] - m) * inv : 0.f;
+      const float ds = pr * (Ss[r * LP + j] - delta) * p.scale;
 #pragma unroll
-      for (int i = 0; i < 64; ++i) dq[i] += ds * Ks[j * 64 + i];
+      for (int i = 0; i < 16; ++i) dq[i] += ds * Ks[j * 64 + d0 + i];
+      // the 4 threads of a row must all have read score / dp of key j before part 0 overwrites them: they are lanes
+      // of one wave executing in lockstep, and the stores below come after this iteration's loads in program order
+      if (part == 0) { Ps[r * LP + j] = pr; Ss[r * LP + j] = ds; }
     }
-    if (row < p.n_q) {
-      char* op = p.dq + ((size_t)b * p.dq_bs + (size_t)row * p.lddq + head * 64) * sizeof(T);
-#pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) *(i32x4*)(op + c8 * 16) = pack8<T>(dq + c8 * 8);
+    if (rok) {
+      char* op = p.dq + ((size_t)b * p.dq_bs + (size_t)row * p.lddq + head * 64 + d0) * sizeof(T);
+      *(i32x4*)(op) = pack8<T>(dq);
+      *(i32x4*)(op + 16) = pack8<T>(dq + 8);
     }
   }
   __syncthreads();
+  // phase 2: thread = 5 keys x 4 head dims of the tile's partial dK / dV (11 LDS reads per 40 FMAs)
   float* out = p.part + ((((size_t)b * p.heads + head) * p.chunks + chunk) * 2) * (size_t)L * 64;
-  for (int e = threadIdx.x; e < L * 64; e += 256) {
-    const int j = e >> 6, d = e & 63;
-    float ak = 0.f, av = 0.f;
+  {
+    const int jb = (threadIdx.x >> 4) * 5, db = (threadIdx.x & 15) * 4;
+    float ak[5][4], av[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { ak[a][c] = 0.f; av[a][c] = 0.f; }
     for (int r = 0; r < 64; ++r) {
-      ak += Ss[r * LP + j] * Qs[r * 65 + d];
-      av += Ps[r * LP + j] * Ds[r * 65 + d];
+      float q4[4], d4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { q4[c] = Qs[r * 65 + db + c]; d4[c] = Ds[r * 65 + db + c]; }
+#pragma unroll
+      for (int a = 0; a < 5; ++a) {
+        const int jj = jb + a < L ? jb + a : L - 1;        // keys past L: computed on a valid address, not stored
+        const float ds = Ss[r * LP + jj], pr = Ps[r * LP + jj];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ak[a][c] += ds * q4[c]; av[a][c] += pr * d4[c]; }
+      }
     }
-    out[e] = ak;
-    out[(size_t)L * 64 + e] = av;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+      if (jb + a < L) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          out[(jb + a) * 64 + db + c] = ak[a][c];
+          out[(size_t)L * 64 + (jb + a) * 64 + db + c] = av[a][c];
+        }
+      }
   }
 }
 
@@ -491,6 +519,7 @@ extern "C" int dfw_cross_attention_bwd(const dfw_xattn_bwd_args* a, dfw_stream_t
   if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->L <= 0) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   if ((a->ldq | a->ldk | a->ldv | a->ldo | a->lddq) % 8 != 0) return DFW_ESHAPE;
+  if (a->L > 80) return DFW_ESHAPE;      // phase 2 tiles the keys as 16 x 5 (77 prompt tokens, T:1368)
   const size_t lds = ((size_t)a->L * 64 * 2 + 2 * 64 * 65 + 2 * 64 * (a->L + 1)) * sizeof(float);
   if (lds > 150 * 1024) return DFW_ESHAPE;
   const int chunks = (a->n_q + 63) / 64;

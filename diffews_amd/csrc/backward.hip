@@ -27,6 +27,7 @@ struct TnP {
   int taps, Hi, Wi, Ho, Wo, stride, pad, ups;
   int splits, mchunk;
   int batch2; long long strideA, strideB, strideA2, strideB2;   // z = (b1 * batch2 + b2) * taps + tap
+  float* out; long long ldo_b, ldo_n, ldo_t; float scale; int accumulate;   // splits == 1: written directly, no slab pass
 };
 
 __device__ __forceinline__ uint32_t tn_off(int row, int ch) {
@@ -134,6 +135,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnP p) {
     cur ^= 1;
   }
   // D layout: col = lane & 31 (k), row = (r & 3) + 8 * (r >> 2) + 4 * lh (n)
+  if (p.splits == 1) {
+    float* o = p.out + (size_t)bb * p.ldo_b + (size_t)tap * p.ldo_t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+        if (k >= p.Kc) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n < p.N) {
+            float* d = o + (size_t)n * p.ldo_n + k;
+            *d = (p.accumulate ? *d : 0.f) + p.scale * acc[i][j][r];
+          }
+        }
+      }
+    return;
+  }
   float* out = p.slab + ((size_t)split * gridDim.z + z) * (size_t)p.N * p.Kc;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -280,23 +300,37 @@ __global__ void gn_bwd_stats_kernel(const GnbP p) {
   }
 }
 
-// one thread per channel: fold chunks per image (kept in part[b][0][c]), then parameter gradients over images
+// fold the pixel chunks per (image, channel): block = 64 channels x 4 chunk lanes, grid (C / 64, B); the sums stay in
+// part[b][0][c]; gn_bwd_param_kernel then adds the images (B terms per channel) into the parameter gradients
 __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const GnbP p) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.C) return;
-  float dg = 0.f, db = 0.f;
-  for (int b = 0; b < p.B; ++b) {
-    float a = 0.f, a2 = 0.f;
-    for (int ch = 0; ch < p.chunks; ++ch) {
+  __shared__ float red[4][64][2];
+  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+  float a = 0.f, a2 = 0.f;
+  if (c < p.C)
+    for (int ch = lane4; ch < p.chunks; ch += 4) {
       const float* o = p.part + (((size_t)b * p.chunks + ch) * p.C + c) * 2;
       a += o[0];
       a2 += o[1];
     }
+  red[lane4][cl][0] = a;
+  red[lane4][cl][1] = a2;
+  __syncthreads();
+  if (lane4 == 0 && c < p.C) {
     float* o0 = p.part + (((size_t)b * p.chunks) * p.C + c) * 2;
-    o0[0] = a;
-    o0[1] = a2;
-    db += a;
-    dg += a2;
+    o0[0] = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+    o0[1] = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const GnbP p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  float dg = 0.f, db = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    const float* o0 = p.part + (((size_t)b * p.chunks) * p.C + c) * 2;
+    db += o0[0];
+    dg += o0[1];
   }
   if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * dg;
   if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * db;
@@ -460,16 +494,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnbP p) {
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const LnbP p) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.C) return;
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const LnbP p) {   // block = 64 channels x 4 lanes over the blocks
+  __shared__ float red[4][64][2];
+  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < p.nblocks; ++k) {
-    a += p.part[((size_t)k * p.C + c) * 2 + 0];
-    b += p.part[((size_t)k * p.C + c) * 2 + 1];
+  if (c < p.C)
+    for (int k = lane4; k < p.nblocks; k += 4) {
+      a += p.part[((size_t)k * p.C + c) * 2 + 0];
+      b += p.part[((size_t)k * p.C + c) * 2 + 1];
+    }
+  red[lane4][cl][0] = a;
+  red[lane4][cl][1] = b;
+  __syncthreads();
+  if (lane4 == 0 && c < p.C) {
+    a = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+    b = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * a;
+    p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * b;
   }
-  p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * a;
-  p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -710,13 +753,15 @@ extern "C" int dfw_gemm_tn(const dfw_gemm_tn_args* a, dfw_stream_t stream) {
   p.strideA = a->strideA; p.strideB = a->strideB; p.strideA2 = a->strideA2; p.strideB2 = a->strideB2;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(((a->N + 127) / 128) * ((a->Kc + 127) / 128), splits, Z);
-  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), grid, dim3(256), 0, st, p);
-  DFW_CHECK_LAUNCH();
   const long long total = (long long)Z * a->N * a->Kc;
   const long long ldo_n = a->ldo_n > 0 ? a->ldo_n : (long long)a->taps * a->Kc;
   const long long ldo_t = a->ldo_t > 0 ? a->ldo_t : a->Kc;
   const long long ldo_b = a->ldo_b > 0 ? a->ldo_b : (long long)a->N * a->taps * a->Kc;
+  p.out = a->out; p.ldo_b = ldo_b; p.ldo_n = ldo_n; p.ldo_t = ldo_t; p.scale = a->scale; p.accumulate = a->accumulate;
+  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  if (splits == 1) return 0;
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, st, (const float*)p.slab, a->out, splits, Z,
                      a->taps, a->N, a->Kc, ldo_b, ldo_n, ldo_t, a->scale, a->accumulate);
   DFW_CHECK_LAUNCH();
@@ -724,8 +769,10 @@ extern "C" int dfw_gemm_tn(const dfw_gemm_tn_args* a, dfw_stream_t stream) {
 }
 
 static void colsum_plan(int rows_per_seg, int& chunks, int& rpc) {
-  chunks = (rows_per_seg + 2047) / 2048;
-  if (chunks > 256) chunks = 256;
+  // 64-row chunks (8 rows per thread) up to 1024 chunks per segment: a [32768][320] activation gradient becomes
+  // 2 x 512 workgroups instead of 2 x 16 (the first version ran 750 launches per step at ~60 us each)
+  chunks = (rows_per_seg + 63) / 64;
+  if (chunks > 1024) chunks = 1024;
   if (chunks < 1) chunks = 1;
   rpc = (rows_per_seg + chunks - 1) / chunks;
   rpc = (rpc + 7) & ~7;
@@ -804,8 +851,12 @@ extern "C" int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t s
   if (bf) hipLaunchKernelGGL((gn_bwd_stats_kernel<__bf16>), grid, dim3(threads), lds, st, p);
   else hipLaunchKernelGGL((gn_bwd_stats_kernel<_Float16>), grid, dim3(threads), lds, st, p);
   DFW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((a->C + 63) / 64, a->B), dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
+  if (a->dgamma || a->dbeta) {
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(a->B * a->groups), dim3(64), 0, st, p);
   DFW_CHECK_LAUNCH();
   if (bf) hipLaunchKernelGGL((gn_bwd_apply_kernel<__bf16>), grid, dim3(threads), 0, st, p);
@@ -816,7 +867,7 @@ extern "C" int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t s
 
 static int lnb_blocks(int rows) {
   int b = (rows + 3) / 4;
-  return b > 512 ? 512 : (b < 1 ? 1 : b);
+  return b > 256 ? 256 : (b < 1 ? 1 : b);
 }
 
 extern "C" size_t dfw_layernorm_bwd_workspace_bytes(int32_t rows, int32_t C) {
@@ -851,7 +902,7 @@ extern "C" int dfw_layernorm_bwd(const dfw_layernorm_bwd_args* a, dfw_stream_t s
     else hipLaunchKernelGGL((ln_bwd_kernel<_Float16, 4>), dim3(nb), dim3(256), lds, st, p);
   }
   DFW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((a->C + 63) / 64), dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
   return 0;
 }

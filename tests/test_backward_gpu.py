@@ -335,3 +335,25 @@ def test_training_loop_loss_decreases_and_matches_torch_adamw(hip_lib):
     # a few % in the loss (measured <= 6.3 %) while following the same curve
     assert all(abs(a - c) < 0.10 * c for a, c in zip(ours, theirs)), (ours, theirs)
     assert poly_lr(1e-4, 100, 100) == pytest.approx(1e-7) and poly_lr(1e-4, 5, 100, warmup_steps=10) == pytest.approx(5e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Bn,heads,N,Lc", [(2, 2, 256, 77), (1, 1, 100, 2), (3, 4, 64, 77)])
+def test_cross_attention_backward(B, dtype, Bn, heads, N, Lc):
+    """attn2 backward (77-token prompt in training, T:1368; 2 tokens at inference) vs torch autograd of SDPA; dk / dv are
+    written into column slices of a wider buffer, as the fused prompt-K/V gradient of all 16 layers is laid out."""
+    ops, ob = B
+    C = heads * 64
+    q, dout = rnd((Bn, N, C), dtype, 1), rnd((Bn, N, C), dtype, 2)
+    kv = rnd((Bn, Lc, 2 * C + 64), dtype, 3)          # this layer's K | V columns inside a wider row
+    qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
+    sh = lambda t: t.reshape(Bn, -1, heads, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(sh(qr), sh(kvr[..., :C]), sh(kvr[..., C:2 * C])).transpose(1, 2).reshape(Bn, N, C)
+    o.backward(dout.float())
+    kvg = kv.cuda()
+    out = ops.cross_attention(q.cuda(), kvg[..., :C], kvg[..., C:2 * C], heads)
+    assert rel(out, o.detach()) < TOL[dtype]
+    dkv = torch.zeros_like(kvg)
+    dq = ob.cross_attention_bwd(q.cuda(), kvg[..., :C], kvg[..., C:2 * C], dout.cuda(), heads, dkv[..., :C], dkv[..., C:2 * C])
+    assert rel(dq, qr.grad) < 2 * TOL[dtype]
+    assert rel(dkv[..., :2 * C], kvr.grad[..., :2 * C]) < 2 * TOL[dtype] and float(dkv[..., 2 * C:].abs().sum()) == 0
