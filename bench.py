@@ -160,6 +160,101 @@ def latest_pmc_summary():
         return os.path.basename(best[1]), json.load(f)
 
 
+def train_main(args):
+    """`--train`: BASELINE configs[4] (train_icl_multitask_nocrop_nearest_nshot_v3.py:1320-1396).  One step per rank =
+    VAE-encode with sampling of the episode's 2s+2 images (T:1347-1358, frozen VAE), lock-step UNet forward over
+    [s support ; 1 query] latents, MSE against -z_mask_tag, backward, bucketed all-reduce of the flat fp32 gradient
+    over the ranks (RCCL; DDP's collective, T:1226-1228), clip_grad_norm_(1) + AdamW + poly LR.  Weak scaling: one
+    episode per GPU per step.  Prints one JSON line (metric: training episodes / second over all ranks)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}")
+    from diffews_amd import build
+    if rank == 0:
+        build.build()
+    import torch.distributed as dist
+    backend = os.environ.get("DFW_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("DFW_ONE_DEVICE") else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"[bench] rank {rank} needs cuda:{dev_index} but this node shows {torch.cuda.device_count()} GPU(s)")
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
+        log(f"[bench] rank {rank}/{dist.get_world_size()} on cuda:{dev_index}, backend {dist.get_backend()}")
+    from diffews_amd import config, episodes, weights
+    from diffews_amd.train import UNetTrainer, allreduce_flat_gradient, poly_lr
+    from diffews_amd.vae import AutoencoderKL
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    s = args.nshot if args.nshot != 1 else 7          # configs[4] is 7-shot unless --nshot says otherwise
+    res = args.res
+    ucfg, vcfg = config.get("tiny_unet" if args.tiny else "sd21_unet"), config.get("tiny_vae" if args.tiny else "sd_vae")
+    t0 = time.time()
+    tr = UNetTrainer(ucfg, weights.synthetic_unet_state_dict(ucfg), torch_dtype=dtype,
+                     loss_scale=1.0 if dtype == torch.bfloat16 else 1024.0)
+    vae = AutoencoderKL(vcfg, weights.synthetic_vae_state_dict(vcfg), torch_dtype=dtype)
+    log(f"[bench] trainer: {tr.P.numel / 1e6:.1f} M parameters (flat fp32 master + grad + AdamW state), build {time.time() - t0:.1f}s")
+    bt = episodes.make_episode_batch(1, s, res, seed=200 + rank, device="cuda")
+    qmask = (bt["query_mask"].float()[:, None].repeat(1, 3, 1, 1) * 2 - 1).contiguous()       # T:1327-1334
+    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    ehs = torch.randn(1, 77, ucfg["cross_attention_dim"], generator=torch.Generator().manual_seed(3)).cuda()   # 77-token prompt (T:1368)
+    sf = 0.18215
+    state = {"step": 0, "loss": None}
+
+    def step():
+        enc = lambda x: vae.encode(x).latent_dist.sample(generator=g) * sf        # T:1347-1358
+        z_ref, z_tag = enc(bt["support_imgs"]), enc(bt["query_img"])
+        z_mref, z_mtag = enc(bt["support_masks"]), enc(qmask)
+        loss, _ = tr.forward_backward(torch.cat([z_ref, z_mref], 1), z_tag, -z_mtag, 1, ehs)   # T:1360-1384
+        allreduce_flat_gradient(tr.P.grad)                                          # T:1391 (DDP)
+        tr.optimizer_step(poly_lr(1e-5, state["step"], 10000), max_grad_norm=1.0)  # T:1393-1395
+        state["step"] += 1
+        state["loss"] = loss
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss = float(state["loss"])
+    log(f"[bench] rank {rank}: {elapsed / args.steps * 1e3:.2f} ms/step, loss {loss:.5f}")
+    if not (loss == loss and abs(loss) < 1e6):
+        raise SystemExit("non-finite loss: invalid run")
+    if rank == 0:
+        line = {"metric": f"training episodes/sec ({res}x{res}, {s}-shot, SD-2 UNet fwd+bwd+AdamW)",
+                "value": round(world * args.steps / elapsed, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"training step, SD-2.1 UNet 865.9 M + frozen SD VAE, {res}x{res}, {s}-shot, 1 episode/GPU/step "
+                                       f"(BASELINE.json configs[4]){' TINY-DEBUG' if args.tiny else ''}",
+                           "nshot": s, "resolution": res, "parallelism": f"data-parallel x{world}, flat fp32 gradient all-reduce in 216 MB buckets",
+                           "optimizer": "clip_grad_norm_(1.0) + AdamW, fp32 master", "hip_graph": False},
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,10 +268,15 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[4] instead of the headline metric: training step (VAE-encode with sampling, UNet "
+                         "fwd+bwd over a 7-shot episode per GPU, gradient all-reduce over the ranks, clip + AdamW)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args.gpus)            # before ANY torch.cuda / HIP call in this process
+    if args.train:
+        return train_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -220,15 +220,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* x, float* part,
   }
 }
 
+// block = 64 columns x 4 lanes over the chunks (fixed order inside a lane, fixed 4-way combine)
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* part, float* out, int chunks, int N, int segs,
                                                           long long ldo, float scale, int accumulate) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)segs * N) return;
-  const int seg = (int)(e / N), n = (int)(e - (long long)seg * N);
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl, seg = blockIdx.y;
   float a = 0.f;
-  for (int c = 0; c < chunks; ++c) a += part[((size_t)seg * chunks + c) * N + n];
-  float* o = out + (size_t)seg * ldo + n;
-  *o = (accumulate ? *o : 0.f) + scale * a;
+  if (n < N)
+    for (int c = lane4; c < chunks; c += 4) a += part[((size_t)seg * chunks + c) * N + n];
+  red[lane4][cl] = a;
+  __syncthreads();
+  if (lane4 == 0 && n < N) {
+    float* o = out + (size_t)seg * ldo + n;
+    *o = (accumulate ? *o : 0.f) + scale * ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -724,7 +730,7 @@ static int tn_plan(const dfw_gemm_tn_args* a, int& splits, int& mchunk, int& Z) 
   long long want = (1024 + tiles - 1) / tiles;       // ~4 workgroups per CU in flight
   if (want > steps) want = steps;
   if (want < 1) want = 1;
-  if (want > 256) want = 256;
+  if (want > 64) want = 64;                          // more splits only lengthen the slab fold
   const int spp = (int)((steps + want - 1) / want);  // 64-row steps per split
   mchunk = spp * 64;
   splits = (a->M + mchunk - 1) / mchunk;
@@ -800,7 +806,7 @@ extern "C" int dfw_colsum(const void* x, float* out, void* workspace, size_t wor
   if (dtype == DFW_BF16) hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, dim3(256), 0, st, (const char*)x, (float*)workspace, (int)rows_per_seg, N, ldx, rpc);
   else hipLaunchKernelGGL((colsum_kernel<_Float16>), grid, dim3(256), 0, st, (const char*)x, (float*)workspace, (int)rows_per_seg, N, ldx, rpc);
   DFW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_fold_kernel, dim3(grid_for((long long)segs * N)), dim3(256), 0, st, (const float*)workspace, out,
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64, segs), dim3(256), 0, st, (const float*)workspace, out,
                      chunks, N, segs, (long long)(ldo > 0 ? ldo : N), scale, accumulate);
   DFW_CHECK_LAUNCH();
   return 0;
