@@ -207,6 +207,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   // whole cache lines -- half the store instructions, no partial-line writes.
   constexpr bool kStage = STAGE >= 8 * 4096;
   auto epilogue = [&](const TileC& c, char* stg, int tile_id) {
+    // ragged N (a multiple of 64, e.g. the UNet's 320 channels on 128-wide tiles): a wave tile is 64 columns, so it
+    // lies entirely inside or entirely outside the matrix -- outside waves (they multiplied zero-filled W rows) skip
+    if (c.n0 + wn * 64 >= p.N) return;
     float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;   // fused GroupNorm sums of this lane's channel pair
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
     auto epilogue6 = [&](const TileC& c, char* stg, int tile_id) {
       // lane-derived indices are recomputed here, behind an opaque copy of the lane id: hoisted to kernel
       // entry (LICM) they live across the K loop and spill at this kernel's 256-register budget
+      if (c.n0 + wn * 64 >= p.N) return;      // ragged N: see epilogue()
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
@@ -708,7 +712,8 @@ static int launch_big(const GemmP& p, hipStream_t st) {
 struct BigCfg { int bm, bn, bk, occ; };
 static bool big_cfg_ok(const GemmP& p, const BigCfg& c) {
   // the 128x128 configuration stores through epi_block (per-quad column guards): ragged N is fine
-  if (c.bm == 128 ? (p.N % 8) != 0 : (p.N % c.bn) != 0) return false;
+  // 128-wide tiles also take N % 64 == 0 (whole 64-column wave tiles; the last column tile is half empty)
+  if (c.bm == 128 ? (p.N % 8) != 0 : (c.bn == 128 ? (p.N % 64) != 0 : (p.N % c.bn) != 0)) return false;
   if ((p.K % c.bk) != 0 || (p.Cin % c.bk) != 0) return false;
   if (p.K / c.bk < 4) return false;
   if (p.taps == 9 && (p.Wo % 16 != 0 || p.Ho % (c.bm / 16) != 0)) return false;
@@ -732,7 +737,11 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   }
   static const BigCfg wide[] = {{256, 256, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
   static const BigCfg narrow[] = {{512, 128, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
-  if ((p.N % 128) == 0) {
+  // DFW_BIG_RAGGED=1: N % 64 == 0 shapes (the UNet's 320 / 960 columns) on the 128-wide tiles too.  Measured neutral
+  // on MI355X (44.01 vs 43.98 ms per step: the half-empty last column tile costs what the bigger tile gains), so
+  // gemm.hip's cost-model tiles keep them by default.
+  static const char* rag = getenv("DFW_BIG_RAGGED");
+  if ((p.N % 128) == 0 || ((p.N % 64) == 0 && p.N > 128 && !p.geglu && rag)) {
     const BigCfg* list = (p.N % 256) == 0 ? wide : narrow;
     for (int i = 0; i < 3; ++i)
       if (big_cfg_ok(p, list[i])) {
