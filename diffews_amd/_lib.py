@@ -110,7 +110,7 @@ class XattnBwdArgs(C.Structure):
 class AdamWArgs(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_sumsq", _vp), ("n", _i64),
                 ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_grad_norm", _f32),
-                ("step", _i32)]
+                ("step", _i32), ("shadow", _vp), ("shadow_dtype", _i32)]
 
 
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
@@ -155,6 +155,7 @@ SYMBOLS = {
     "dfw_silu": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "dfw_sumsq": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "dfw_adamw": (_i32, [C.POINTER(AdamWArgs), _vp]),
+    "dfw_weight_relayout": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp]),
     "dfw_resample_ksize": (_i32, [_i32, _i32]),
     "dfw_resample_coeffs": (_i32, [_i32, _i32, _vp, _vp]),
     "dfw_image_to_tensor": (_i32, [C.POINTER(ImageArgs), _vp]),

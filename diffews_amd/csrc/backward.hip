@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* part,
 // AdamW (torch.optim.AdamW, T:1186-1194: decoupled weight decay) on flat fp32 master parameters, with the
 // clip_grad_norm_ factor (T:1393) read from device memory: g *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)).
 struct AdamP {
-  float* p; const float* g; float* m; float* v; const float* sumsq;
+  float* p; const float* g; float* m; float* v; const float* sumsq; void* shadow; int shadow_bf16;
   long long n;
   float lr, beta1, beta2, eps, wd, bc1, bc2, max_norm;
 };
@@ -698,6 +698,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamP a) {
     const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
     w -= (a.lr / a.bc1) * (m / denom);
     a.p[e] = w;
+    if (a.shadow) {        // the 16-bit copy the MFMA kernels read, refreshed in the same pass
+      if (a.shadow_bf16) ((__bf16*)a.shadow)[e] = (__bf16)w;
+      else ((_Float16*)a.shadow)[e] = (_Float16)w;
+    }
+  }
+}
+
+// y[(flip ? nb - 1 - b : b)][c][r] = x[b][r][c]   (16-bit elements; x rows at ldx / matrices at x_bs, y likewise):
+// W^T of a Linear for its data-gradient GEMM (nb = 1) and, with nb = 9 and flip, the tap-mirrored channel-swapped
+// conv3x3 weight  W'[ci][8 - tap][co] = W[co][tap][ci].  64 x 64 tiles through LDS, 16-byte global accesses.
+__global__ __launch_bounds__(256) void relayout_kernel(const uint16_t* x, uint16_t* y, int R, int C, long long ldx,
+                                                       long long ldy, long long x_bs, long long y_bs, int nb, int flip) {
+  __shared__ uint16_t tile[64][72];
+  const int b = blockIdx.z, yb = flip ? nb - 1 - b : b;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const uint16_t* xs = x + (size_t)b * x_bs;
+  uint16_t* ys = y + (size_t)yb * y_bs;
+  for (int e = threadIdx.x; e < 64 * 8; e += 256) {        // 64 rows x 8 chunks of 8 elements
+    const int i = e >> 3, ch = e & 7, r = r0 + i, c = c0 + ch * 8;
+    i32x4 v = {0, 0, 0, 0};
+    if (r < R && c < C) v = *(const i32x4*)(xs + (size_t)r * ldx + c);
+    *(i32x4*)(&tile[i][ch * 8]) = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 8; e += 256) {        // output row = input column
+    const int i = e >> 3, ch = e & 7, c = c0 + i, r = r0 + ch * 8;
+    if (c < C && r < R) {
+      uint16_t o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = tile[ch * 8 + k][i];
+      *(i32x4*)(ys + (size_t)c * ldy + r) = *(const i32x4*)o;
+    }
   }
 }
 
@@ -992,11 +1024,25 @@ extern "C" int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream) {
   if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || a->n <= 0 || a->step <= 0) return DFW_EINVAL;
   AdamP p;
   p.p = a->param; p.g = a->grad; p.m = a->exp_avg; p.v = a->exp_avg_sq; p.sumsq = a->grad_sumsq;
+  p.shadow = a->shadow; p.shadow_bf16 = a->shadow_dtype == DFW_BF16;
+  if (a->shadow && a->shadow_dtype != DFW_BF16 && a->shadow_dtype != DFW_F16) return DFW_EINVAL;
   p.n = a->n; p.lr = a->lr; p.beta1 = a->beta1; p.beta2 = a->beta2; p.eps = a->eps; p.wd = a->weight_decay;
   p.bc1 = 1.0f - powf(a->beta1, (float)a->step);
   p.bc2 = 1.0f - powf(a->beta2, (float)a->step);
   p.max_norm = a->max_grad_norm;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n, 8192)), dim3(256), 0, (hipStream_t)stream, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_weight_relayout(const void* x, void* y, int32_t R, int32_t C, int64_t ldx, int64_t ldy, int32_t nb,
+                                   int64_t x_bs, int64_t y_bs, int32_t flip, dfw_stream_t stream) {
+  if (!x || !y || R <= 0 || C <= 0 || nb <= 0) return DFW_EINVAL;
+  if ((R % 8) || (C % 8) || (ldx % 8) || (ldy % 8) || (x_bs % 8) || (y_bs % 8)) return DFW_ESHAPE;
+  if (((uintptr_t)x | (uintptr_t)y) & 15) return DFW_ESHAPE;
+  dim3 grid((C + 63) / 64, (R + 63) / 64, nb);
+  hipLaunchKernelGGL(relayout_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, R, C,
+                     (long long)ldx, (long long)ldy, (long long)x_bs, (long long)y_bs, nb, flip);
   DFW_CHECK_LAUNCH();
   return 0;
 }

@@ -251,8 +251,27 @@ def sumsq(x):
     return out
 
 
+def linear_wt(w):
+    """W [N, K] (storage dtype, contiguous) -> W^T [K, N]: the weight of the data-gradient GEMM dX = dY W."""
+    assert w.dim() == 2 and w.is_contiguous()
+    N, K = w.shape
+    y = torch.empty(K, N, dtype=w.dtype, device=w.device)
+    L.check(L.lib().dfw_weight_relayout(w.data_ptr(), y.data_ptr(), N, K, K, N, 1, 0, 0, 0, _stream()), "dfw_weight_relayout")
+    return y
+
+
+def conv3x3_wd(w, cout):
+    """packed conv weight [Cout, 9*Cin] -> [Cin, 9*Cout] with mirrored taps (packing.pack_conv3x3_dgrad on device)."""
+    assert w.dim() == 2 and w.is_contiguous() and w.shape[0] == cout
+    cin = w.shape[1] // 9
+    y = torch.empty(cin, 9 * cout, dtype=w.dtype, device=w.device)
+    L.check(L.lib().dfw_weight_relayout(w.data_ptr(), y.data_ptr(), cout, cin, 9 * cin, 9 * cout, 9, cin, cout, 1, _stream()),
+            "dfw_weight_relayout")
+    return y
+
+
 def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_sumsq=None,
-          max_grad_norm=0.0):
+          max_grad_norm=0.0, shadow=None):
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
     a = L.AdamWArgs()
@@ -260,4 +279,7 @@ def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e
     a.grad_sumsq = _p(grad_sumsq)
     a.n, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = param.numel(), lr, betas[0], betas[1], eps, weight_decay
     a.max_grad_norm, a.step = max_grad_norm, step
+    if shadow is not None:
+        assert shadow.numel() == param.numel() and shadow.is_contiguous()
+        a.shadow, a.shadow_dtype = shadow.data_ptr(), _dt(shadow)
     L.check(L.lib().dfw_adamw(C.byref(a), _stream()), "dfw_adamw")

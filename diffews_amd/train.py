@@ -9,7 +9,8 @@ Counterpart of the hot loop of
 as ONE lock-step trunk pass over the batch [support images ; query images] (same arithmetic per image as the two
 passes, see unet.forward_pair), a hand-written backward through the same graph, and a fused AdamW on flat fp32
 buffers.  All compute is libdiffews_hip.so (ops.py / ops_bwd.py); torch is device memory, streams and -- once per
-optimizer step -- the re-layout of the 16-bit weight copies the data-gradient GEMMs read (transposes / tap mirrors).
+optimizer step -- nothing else: the 16-bit shadow is written by the AdamW kernel and the transposed / tap-mirrored copies the
+data-gradient GEMMs read by dfw_weight_relayout.
 
 Parameters live in ONE flat fp32 master buffer in the engine's PACKED layouts (conv [Cout][ky][kx][Cin], fused
 [Wq;Wk;Wv], fused prompt [Wk2;Wv2] of all layers, the 22 time_emb_proj layers as one matrix, GEGLU rows interleaved),
@@ -316,11 +317,7 @@ class UNetTrainer:
         key = (kind, name)
         if key not in self._derived:
             w = self.P.w(name)
-            if kind == "T":
-                self._derived[key] = w.t().contiguous()
-            else:
-                co = w.shape[0]
-                self._derived[key] = w.view(co, 9, -1).flip(1).permute(2, 1, 0).reshape(-1, 9 * co).contiguous()
+            self._derived[key] = ob.linear_wt(w) if kind == "T" else ob.conv3x3_wd(w, w.shape[0])
         return self._derived[key]
 
     # ------------------------------------------------------------------ ops with registered backward
@@ -566,8 +563,8 @@ class UNetTrainer:
         self.step_count += 1
         ss = ob.sumsq(P.grad) if max_grad_norm and max_grad_norm > 0 else None
         ob.adamw(P.master, P.grad, P.exp_avg, P.exp_avg_sq, self.step_count, lr, betas, eps, weight_decay, grad_sumsq=ss,
-                 max_grad_norm=max_grad_norm or 0.0)
-        P.sync_shadow()
+                 max_grad_norm=max_grad_norm or 0.0, shadow=P.shadow)      # the 16-bit shadow is refreshed in the same pass
+        P.version += 1
         return ss
 
 

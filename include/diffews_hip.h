@@ -433,9 +433,18 @@ typedef struct {
   int64_t n;
   float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
   int32_t step;
+  /* Optional: storage-dtype copy of the updated parameters (what the MFMA kernels read), written in the same pass. */
+  void* shadow; int32_t shadow_dtype;
 } dfw_adamw_args;
 
 int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream);
+
+/* 16-bit weight re-layout for the data-gradient GEMMs: y[(flip ? nb-1-b : b)][c][r] = x[b][r][c], matrices of R x C
+ * elements with row strides ldx / ldy and matrix strides x_bs / y_bs (all multiples of 8 elements).
+ *   Linear:  nb = 1            -> W^T ([K][N] read by dfw_gemm as the weight of dX = dY W)
+ *   conv3x3: nb = 9, flip != 0 -> W'[Cin][8 - tap][Cout] = W[Cout][tap][Cin] (x_bs = Cin, ldx = 9*Cin, y_bs = Cout, ldy = 9*Cout) */
+int dfw_weight_relayout(const void* x, void* y, int32_t R, int32_t C, int64_t ldx, int64_t ldy, int32_t nb, int64_t x_bs,
+                        int64_t y_bs, int32_t flip, dfw_stream_t stream);
 
 #ifdef __cplusplus
 }

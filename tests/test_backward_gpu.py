@@ -357,3 +357,16 @@ def test_cross_attention_backward(B, dtype, Bn, heads, N, Lc):
     dq = ob.cross_attention_bwd(q.cuda(), kvg[..., :C], kvg[..., C:2 * C], dout.cuda(), heads, dkv[..., :C], dkv[..., C:2 * C])
     assert rel(dq, qr.grad) < 2 * TOL[dtype]
     assert rel(dkv[..., :2 * C], kvr.grad[..., :2 * C]) < 2 * TOL[dtype] and float(dkv[..., 2 * C:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_relayout(B, dtype):
+    """Device re-layouts of the 16-bit weights for the data-gradient GEMMs == the host packing functions."""
+    ops, ob = B
+    from diffews_amd.packing import pack_conv3x3, pack_conv3x3_dgrad
+    w = rnd((320, 1288), dtype, 1)
+    assert torch.equal(ob.linear_wt(w.cuda()).cpu(), w.t().contiguous())
+    cw = rnd((128, 64, 3, 3), dtype, 2)
+    assert torch.equal(ob.conv3x3_wd(pack_conv3x3(cw).cuda(), 128).cpu(), pack_conv3x3_dgrad(cw))
+    cw = rnd((8, 320, 3, 3), dtype, 3)
+    assert torch.equal(ob.conv3x3_wd(pack_conv3x3(cw).cuda(), 8).cpu(), pack_conv3x3_dgrad(cw))
