@@ -147,5 +147,8 @@ int launch_conv_halo(const GemmP& p, hipStream_t st);  // conv_halo.hip
 int conv_halo_gn_chunks(const GemmP& p);
 bool conv_halo_gn_input_ok(const GemmP& p);
 bool conv_halo_eligible(const GemmP& p, int& bn);
+int launch_conv_patch(const GemmP& p, hipStream_t st);  // conv_patch.hip
+bool conv_patch_eligible(const GemmP& p, int& bm, int& bn);
+int conv_patch_gn_chunks(const GemmP& p);
 
 }  // namespace dfw

@@ -127,6 +127,40 @@ def test_conv3x3_big_tiles(ops, dtype, B, H, W, Cin, Cout, ups):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 512, 512, 128, 128), (2, 256, 256, 64, 128), (1, 320, 336, 64, 128),
+                                            (3, 512, 256, 64, 384)])
+def test_conv3x3_patch_tiles(ops, dtype, B, H, W, Cin, Cout):
+    """Shapes the LDS-resident-patch kernel (conv_patch.hip, 512 x 128 tile) takes by default: result against torch
+    fp32 on the same 16-bit inputs (first and last image, all four borders), with residual, per-image bias and
+    output scale in the epilogue, and its fused GroupNorm sums against a separate pass."""
+    from diffews_amd.packing import pack_conv3x3
+    names = []
+    ops.gemm_hook = lambda name, *a: names.append(name)
+    try:
+        x = rnd((B, H, W, Cin), dtype, 1).cuda()
+        w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5).cuda()
+        bias, rb = torch.randn(Cout).cuda(), torch.randn(B, Cout).cuda()
+        res = rnd((B, H, W, Cout), dtype, 3).cuda()
+        y = ops.conv3x3(x, pack_conv3x3(w.cpu()).cuda(), Cout, bias=bias, rowbias=rb, residual=res, out_scale=0.5,
+                        gn_groups=32)
+    finally:
+        ops.gemm_hook = None
+    assert names and names[0].startswith("conv_patch_kernel"), names
+    for i in {0, B - 1}:
+        ref = F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rb[i][None, :, None, None]
+        ref = ((ref.permute(0, 2, 3, 1) + res[i:i + 1].float()) * 0.5).cpu()
+        assert rel(y[i:i + 1].cpu(), ref) < TOL[dtype]
+    if Cout // 32 & (Cout // 32 - 1):                  # 12 channels per group: no fused sums, groupnorm() takes its own
+        assert getattr(y, "_gn_stats", None) is None
+        return
+    part, chunks, groups = y._gn_stats
+    g, b = (torch.randn(Cout) * 0.2 + 1).cuda(), (torch.randn(Cout) * 0.2).cuda()
+    fused = ops.groupnorm(y, g, b, 32, 1e-6, silu=True)
+    plain = ops.groupnorm(y.clone(), g, b, 32, 1e-6, silu=True)
+    assert rel(fused.cpu(), plain.cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 128, 128, 64, 256), (3, 128, 128, 64, 128), (2, 128, 192, 128, 512)])
 def test_conv_fused_groupnorm_stats(ops, dtype, B, H, W, Cin, Cout):
     """GroupNorm statistics emitted by the producing conv's epilogue == a separate statistics pass."""
