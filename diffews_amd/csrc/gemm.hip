@@ -470,16 +470,16 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
   int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
-  if (conv_halo_eligible(p, halo_bn)) {
-    snprintf(buf, n, "conv_halo_kernel<%s,256,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", halo_bn, p.gn_coef ? ",gn_in" : "");
-    return 0;
-  }
   {
     int pbm = 0, pbn = 0;
     if (conv_patch_eligible(p, pbm, pbn)) {
-      snprintf(buf, n, "conv_patch_kernel<%s,%d,%d>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbm, pbn);
+      snprintf(buf, n, "conv_patch_kernel<%s,%d,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbm, pbn, p.gn_coef ? ",gn_in" : "");
       return 0;
     }
+  }
+  if (conv_halo_eligible(p, halo_bn)) {
+    snprintf(buf, n, "conv_halo_kernel<%s,256,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", halo_bn, p.gn_coef ? ",gn_in" : "");
+    return 0;
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
     snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d%s,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,
@@ -495,10 +495,9 @@ extern "C" int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a) {
   GemmP p;
   int esz;
   if (fill_params(a, p, esz)) return 0;
-  int halo_bn = 0;
-  if (conv_halo_eligible(p, halo_bn)) return conv_halo_gn_chunks(p);
-  int pbm = 0, pbn = 0;
+  int halo_bn = 0, pbm = 0, pbn = 0;
   if (conv_patch_eligible(p, pbm, pbn)) return conv_patch_gn_chunks(p);
+  if (conv_halo_eligible(p, halo_bn)) return conv_halo_gn_chunks(p);
   return gemm_big_gn_chunks(p);
 }
 
@@ -506,6 +505,8 @@ extern "C" int32_t dfw_gemm_gn_input_ok(const dfw_gemm_args* a) {
   GemmP p;
   int esz;
   if (fill_params(a, p, esz)) return 0;
+  int pbm = 0, pbn = 0;
+  if (p.gn_coef && conv_patch_eligible(p, pbm, pbn)) return 1;
   return conv_halo_gn_input_ok(p) ? 1 : 0;
 }
 
@@ -526,12 +527,12 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
-  if (conv_halo_eligible(p, halo_bn)) return launch_conv_halo(p, st);
-  if (p.gn_coef) return DFW_ESHAPE;   // no other kernel normalises its input
   {
     int pbm = 0, pbn = 0;
     if (conv_patch_eligible(p, pbm, pbn)) return launch_conv_patch(p, st);
   }
+  if (conv_halo_eligible(p, halo_bn)) return launch_conv_halo(p, st);
+  if (p.gn_coef) return DFW_ESHAPE;   // no other kernel normalises its input
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
 }

@@ -181,7 +181,8 @@ def test_conv_fused_groupnorm_stats(ops, dtype, B, H, W, Cin, Cout):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("silu", [True, False])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 160, 160, 64, 128), (3, 128, 128, 128, 256), (1, 224, 224, 256, 512),
-                                            (7, 96, 112, 128, 128)])
+                                            (7, 96, 112, 128, 128), (1, 512, 512, 128, 128), (3, 256, 256, 64, 128),
+                                            (2, 256, 256, 256, 256)])
 def test_conv_fused_groupnorm_input(ops, dtype, silu, B, H, W, Cin, Cout):
     """conv3x3(gn_in=...) normalises its input patch in LDS (ResnetBlock2D norm+SiLU+conv in one kernel):
     matches dfw_groupnorm followed by the conv, image borders (zero padding of the NORMALISED
