@@ -169,6 +169,175 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnP p) {
     }
 }
 
+// Same mathematics, fragments and LDS image as gemm_tn_kernel, different data movement and tile size.
+//   * Output tile (NSA * 128) x (NSB * 128): 128 x 128 moves one operand byte per 64 FLOP through L2 -> LDS and tops out
+//     near 0.65 PFLOP/s however large the problem (measured: ~10 TB/s of L2 reads); 256 x 256 halves that.  Every wave
+//     owns a 64 x 64 block (4 accumulator tiles), so a workgroup has 4 * NSA * NSB waves.
+//   * The operands arrive by LDS-DMA into a ring: stage = 32 reduction rows of every 128-column sub-tile (8 KiB each,
+//     256-byte rows, the tn_off image), S = 4 stages, three in flight across the single barrier of a step behind a
+//     counted s_waitcnt vmcnt (the wave's own DPS instructions per stage).  One DMA instruction covers 4 rows x 256 B of
+//     one sub-tile: lane -> row lane >> 4, LDS slot lane & 15; the tn_off swizzle sits on the SOURCE chunk (LDS is written
+//     linearly): slot c of row r holds chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3)).  Instruction g = j * NW + wave of a
+//     stage covers rows 4 * (g & 7) .. + 4 of sub-tile g >> 3, and NW is a multiple of 4, so (r >> 2) & 3 = wave & 3:
+//     the source chunk is the lane constant c ^ (((lane >> 4) << 2) | (wave & 3)).
+//   * CONV: the im2col gather keeps (image, oy, ox) of each of the lane's rows and advances them by 32 rows per stage with
+//     predicated wraps (Wo >= 8 and Ho * Wo >= 32, checked on the host) -- no division, no divergent branch in the loop.
+template <typename T, int NSA, int NSB, bool CONV>
+__global__ __launch_bounds__(256 * NSA * NSB) void gemm_tn_ring_kernel(const TnP p) {
+  constexpr int BKR = 32, S = 4, SUB = BKR * 256, NSUB = NSA + NSB, STAGE = NSUB * SUB;
+  constexpr int NW = 4 * NSA * NSB, DPS = NSUB * 8 / NW;
+  static_assert(NSUB * 8 % NW == 0, "DMA instructions divide evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / (2 * NSB), wk = wave % (2 * NSB);          // 64-column block of the tile along n / along k
+  const int lh = lane >> 5;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int ntk = (p.Kc + NSB * 128 - 1) / (NSB * 128);
+  const int n0 = ((int)blockIdx.x / ntk) * (NSA * 128), k0 = ((int)blockIdx.x % ntk) * (NSB * 128);
+  const int split = blockIdx.y, z = blockIdx.z;
+  const int tap = z % p.taps, bb = z / p.taps;
+  const int b1 = bb / p.batch2, b2 = bb - b1 * p.batch2;
+  const char* Ab = p.A + ((size_t)b1 * p.strideA + (size_t)b2 * p.strideA2) * sizeof(T);
+  const char* Bb = p.B + ((size_t)b1 * p.strideB + (size_t)b2 * p.strideB2) * sizeof(T);
+  const u32x4 ra = make_srd(Ab, p.a_bytes), rb = make_srd(Bb, p.b_bytes);
+  const uint32_t lds0 = lds_addr(smem);
+  const int m_begin = split * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
+  const int nsteps = (m_end - m_begin + BKR - 1) / BKR;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const int limH = p.ups ? 2 * p.Hi : p.Hi, limW = p.ups ? 2 * p.Wi : p.Wi;
+  const int ush = p.ups ? 1 : 0;
+
+  // ---- loader state per DMA instruction of a stage: column offset (fixed), row, and (CONV, B operand) its pixel
+  const int ch = (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3));
+  uint32_t colb[DPS];                      // byte offset of the lane's 16 bytes inside its row, kOOB if out of range
+  int lm[DPS], loy[DPS], lox[DPS], limg[DPS];
+#pragma unroll
+  for (int j = 0; j < DPS; ++j) {
+    const int g = j * NW + wave, t = g >> 3;
+    const bool isA = t < NSA;
+    const int col = isA ? n0 + t * 128 + ch * 8 : k0 + (t - NSA) * 128 + ch * 8;
+    colb[j] = col < (isA ? p.N : p.Kc) ? (uint32_t)col * (uint32_t)sizeof(T) : kOOB;
+    lm[j] = m_begin + 4 * (g & 7) + (lane >> 4);
+    limg[j] = loy[j] = lox[j] = 0;
+    if (CONV && !isA) {
+      const int hw = p.Ho * p.Wo;
+      limg[j] = lm[j] / hw;
+      const int rem = lm[j] - limg[j] * hw;
+      loy[j] = rem / p.Wo;
+      lox[j] = rem - loy[j] * p.Wo;
+    }
+  }
+  int ld_slot = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    const uint32_t dst = lds0 + (uint32_t)ld_slot * STAGE;
+    ld_slot = (ld_slot + 1) & (S - 1);
+#pragma unroll
+    for (int j = 0; j < DPS; ++j) {
+      const int g = j * NW + wave, t = g >> 3;
+      const bool isA = t < NSA;                       // wave-uniform
+      const bool okm = lm[j] < m_end && colb[j] != kOOB;
+      uint32_t off;
+      if (isA) {
+        off = (uint32_t)((size_t)lm[j] * p.lda * sizeof(T)) + colb[j];
+      } else if (!CONV) {
+        off = (uint32_t)((size_t)lm[j] * p.ldb * sizeof(T)) + colb[j];
+      } else {
+        int iy = loy[j] * p.stride - p.pad + ky, ix = lox[j] * p.stride - p.pad + kx;
+        const bool in = (unsigned)iy < (unsigned)limH && (unsigned)ix < (unsigned)limW;
+        iy >>= ush;
+        ix >>= ush;
+        off = (uint32_t)((((size_t)limg[j] * p.Hi + iy) * p.Wi + ix) * p.ldb * sizeof(T)) + colb[j];
+        off = in ? off : kOOB;
+        lox[j] += BKR;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const bool wr = lox[j] >= p.Wo;
+          lox[j] -= wr ? p.Wo : 0;
+          loy[j] += wr ? 1 : 0;
+        }
+        const bool wi = loy[j] >= p.Ho;
+        loy[j] -= wi ? p.Ho : 0;
+        limg[j] += wi ? 1 : 0;
+      }
+      dma16(isA ? ra : rb, okm ? off : kOOB, dst + (uint32_t)g * 1024u);
+      lm[j] += BKR;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int issued = 0;
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i)
+    if (issued < nsteps) { issue(); ++issued; }
+  const int a_sub = (wn >> 1) * SUB, b_sub = (NSA + (wk >> 1)) * SUB;   // this wave's sub-tiles inside a stage
+  const int wn1 = wn & 1, wk1 = wk & 1;
+  for (int s = 0; s < nsteps; ++s) {
+    const int younger = issued - s - 1;
+    if (younger >= 2) wait_vm<2 * DPS>();
+    else if (younger == 1) wait_vm<DPS>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < nsteps) { issue(); ++issued; }
+    const char* at = smem + (s & (S - 1)) * STAGE + a_sub;
+    const char* bt = smem + (s & (S - 1)) * STAGE + b_sub;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      typename Tr<T>::v8 fa[2], fb[2];
+      const int r0 = ss * 16 + 8 * lh + tq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ca = wn1 * 8 + i * 4 + 2 * tg + (tp >> 1), cb = wk1 * 8 + i * 4 + 2 * tg + (tp >> 1);
+        const typename Tr<T>::v4 alo = lds_tr_read<T>(at + tn_off(r0, ca) + 8 * (tp & 1));
+        const typename Tr<T>::v4 ahi = lds_tr_read<T>(at + tn_off(r0 + 4, ca) + 8 * (tp & 1));
+        const typename Tr<T>::v4 blo = lds_tr_read<T>(bt + tn_off(r0, cb) + 8 * (tp & 1));
+        const typename Tr<T>::v4 bhi = lds_tr_read<T>(bt + tn_off(r0 + 4, cb) + 8 * (tp & 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fa[i][j] = alo[j]; fa[i][4 + j] = ahi[j]; fb[i][j] = blo[j]; fb[i][4 + j] = bhi[j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Tr<T>::mfma(fa[i], fb[j], acc[i][j]);
+    }
+  }
+  // D layout: col = lane & 31 (k), row = (r & 3) + 8 * (r >> 2) + 4 * lh (n)
+  float* o;
+  long long ldn;
+  float sc;
+  bool accum;
+  if (p.splits == 1) {
+    o = p.out + (size_t)bb * p.ldo_b + (size_t)tap * p.ldo_t;
+    ldn = p.ldo_n; sc = p.scale; accum = p.accumulate != 0;
+  } else {
+    o = p.slab + ((size_t)split * gridDim.z + z) * (size_t)p.N * p.Kc;
+    ldn = p.Kc; sc = 1.f; accum = false;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+      if (k >= p.Kc) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < p.N) {
+          float* d = o + (size_t)n * ldn + k;
+          *d = (accum ? *d : 0.f) + sc * acc[i][j][r];
+        }
+      }
+    }
+}
+
 // out[b * ldo_b + n * ldo_n + tap * ldo_t + k] (+)= scale * sum_s slab[s][z][n][k], z = b * taps + tap
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, float* out, int splits, int Z, int taps, int N,
                                                         int Kc, long long ldo_b, long long ldo_n, long long ldo_t,
@@ -744,7 +913,16 @@ static int grid_for(long long items, int cap = 4096) {
   return (int)b;
 }
 
-static int tn_plan(const dfw_gemm_tn_args* a, int& splits, int& mchunk, int& Z) {
+// Plan of one TN GEMM: tile (nsa x 128) x (nsb x 128), ring or register-staged kernel, split of M.
+struct TnPlan { int nsa, nsb, splits, mchunk, Z; bool ring, conv; };
+
+static int tn_tile_dim(int d) {           // 256-wide tiles where they waste at most 20 % of their columns
+  if (d < 256) return 1;
+  const int t = (d + 255) / 256 * 256;
+  return t * 4 <= d * 5 ? 2 : 1;
+}
+
+static int tn_plan(const dfw_gemm_tn_args* a, TnPlan& pl) {
   if (!a || !a->A || !a->B || !a->out) return DFW_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->Kc <= 0) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
@@ -756,29 +934,80 @@ static int tn_plan(const dfw_gemm_tn_args* a, int& splits, int& mchunk, int& Z) 
   }
   if (a->a_elems <= 0 || a->b_elems <= 0 || a->a_elems >= (1ll << 30) || a->b_elems >= (1ll << 30)) return DFW_ERANGE;
   const int b1 = a->batch > 1 ? a->batch : 1, b2 = a->batch2 > 1 ? a->batch2 : 1;
-  Z = b1 * b2 * a->taps;
-  const long long tiles = (long long)((a->N + 127) / 128) * ((a->Kc + 127) / 128) * Z;
-  const int steps = (a->M + 63) / 64;
-  long long want = (1024 + tiles - 1) / tiles;       // ~4 workgroups per CU in flight
-  if (want > steps) want = steps;
-  if (want < 1) want = 1;
-  if (want > 64) want = 64;                          // more splits only lengthen the slab fold
-  const int spp = (int)((steps + want - 1) / want);  // 64-row steps per split
-  mchunk = spp * 64;
-  splits = (a->M + mchunk - 1) / mchunk;
+  pl.Z = b1 * b2 * a->taps;
+  pl.conv = a->taps == 9;
+  static const char* ring_env = getenv("DFW_TN_RING");          // 0: register-staged 128 x 128 kernel only; 1: ring, 128 x 128 only
+  pl.ring = (!ring_env || ring_env[0] != '0') && (!pl.conv || (a->Wo >= 8 && a->Ho * a->Wo >= 32));
+  const bool big = pl.ring && !(ring_env && ring_env[0] == '1');
+  pl.nsa = big ? tn_tile_dim(a->N) : 1;
+  pl.nsb = big ? tn_tile_dim(a->Kc) : 1;
+  const long long tiles = (long long)((a->N + pl.nsa * 128 - 1) / (pl.nsa * 128)) * ((a->Kc + pl.nsb * 128 - 1) / (pl.nsb * 128)) * pl.Z;
+  // Split of M: every split costs a fp32 slab of N x Kc (written once, read once by the fold), every workgroup a fixed
+  // start-up / store tail; few splits leave CUs idle.  Minimise  rounds * (steps / splits * t_step + t_fixed) + slab time
+  // over the split count (times in us; t_step = one 32-row step of a workgroup at the occupancy the tile allows, from
+  // scratch/bench_tn2.py on MI355X).
+  const int nsub = pl.nsa + pl.nsb;
+  const int slots = 256 * (nsub == 2 ? 2 : 1);                  // workgroups resident at once (LDS: 32 KiB x sub-tiles)
+  const double t_step = pl.ring ? (nsub == 2 ? 0.8 : nsub == 3 ? 0.75 : 1.1) : 1.6, t_fixed = 4.0, slab_bw = 3.0e6;
+  const int steps = (a->M + 31) / 32;
+  const int smax = steps / 4 < 1 ? 1 : (steps / 4 > 64 ? 64 : steps / 4);
+  double best = 1e30;
+  int best_s = 1;
+  for (int sp = 1; sp <= smax; ++sp) {
+    const int spp = (steps + sp - 1) / sp;
+    const int real = (steps + spp - 1) / spp;
+    const long long rounds = (tiles * real + slots - 1) / slots;
+    const double slab = real > 1 ? 2.0 * real * pl.Z * (double)a->N * a->Kc * 4.0 / slab_bw + 4.0 : 0.0;
+    const double tt = rounds * (spp * t_step + t_fixed) + slab;
+    if (tt < best) { best = tt; best_s = sp; }
+  }
+  int spp = (steps + best_s - 1) / best_s;
+  if (!pl.ring) spp = (spp + 1) & ~1;                            // the register-staged kernel walks 64-row steps
+  pl.mchunk = spp * 32;
+  pl.splits = (a->M + pl.mchunk - 1) / pl.mchunk;
   return 0;
 }
 
 extern "C" size_t dfw_gemm_tn_workspace_bytes(const dfw_gemm_tn_args* a) {
-  int splits, mchunk, Z;
-  if (tn_plan(a, splits, mchunk, Z)) return 0;
-  return (size_t)splits * Z * a->N * a->Kc * sizeof(float);
+  TnPlan pl;
+  if (tn_plan(a, pl)) return 0;
+  return (size_t)pl.splits * pl.Z * a->N * a->Kc * sizeof(float);
+}
+
+template <typename T, int NSA, int NSB, bool CONV>
+static void launch_tn_ring(const TnP& p, dim3 grid, hipStream_t st) {
+  constexpr int lds = 4 * (NSA + NSB) * 32 * 256;
+  auto kfn = gemm_tn_ring_kernel<T, NSA, NSB, CONV>;
+  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kfn, grid, dim3(256 * NSA * NSB), lds, st, p);
+}
+
+template <typename T>
+static void launch_tn(const TnP& p, const TnPlan& pl, dim3 grid, hipStream_t st) {
+  if (!pl.ring) { hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), 0, st, p); return; }
+  const int cfg = (pl.nsa - 1) * 2 + (pl.nsb - 1);
+  if (pl.conv) {
+    switch (cfg) {
+      case 0: launch_tn_ring<T, 1, 1, true>(p, grid, st); break;
+      case 1: launch_tn_ring<T, 1, 2, true>(p, grid, st); break;
+      case 2: launch_tn_ring<T, 2, 1, true>(p, grid, st); break;
+      default: launch_tn_ring<T, 2, 2, true>(p, grid, st); break;
+    }
+  } else {
+    switch (cfg) {
+      case 0: launch_tn_ring<T, 1, 1, false>(p, grid, st); break;
+      case 1: launch_tn_ring<T, 1, 2, false>(p, grid, st); break;
+      case 2: launch_tn_ring<T, 2, 1, false>(p, grid, st); break;
+      default: launch_tn_ring<T, 2, 2, false>(p, grid, st); break;
+    }
+  }
 }
 
 extern "C" int dfw_gemm_tn(const dfw_gemm_tn_args* a, dfw_stream_t stream) {
-  int splits, mchunk, Z;
-  int rc = tn_plan(a, splits, mchunk, Z);
+  TnPlan pl;
+  int rc = tn_plan(a, pl);
   if (rc) return rc;
+  const int splits = pl.splits, Z = pl.Z;
   if (!a->workspace || a->workspace_bytes < (size_t)splits * Z * a->N * a->Kc * sizeof(float)) return DFW_EWORKSPACE;
   TnP p;
   p.A = (const char*)a->A; p.B = (const char*)a->B; p.slab = (float*)a->workspace;
@@ -786,18 +1015,18 @@ extern "C" int dfw_gemm_tn(const dfw_gemm_tn_args* a, dfw_stream_t stream) {
   p.M = a->M; p.N = a->N; p.Kc = a->Kc; p.lda = a->lda; p.ldb = a->ldb;
   p.taps = a->taps; p.Hi = a->Hi; p.Wi = a->Wi; p.Ho = a->Ho; p.Wo = a->Wo;
   p.stride = a->stride; p.pad = a->pad; p.ups = a->ups;
-  p.splits = splits; p.mchunk = mchunk;
+  p.splits = splits; p.mchunk = pl.mchunk;
   p.batch2 = a->batch2 > 1 ? a->batch2 : 1;
   p.strideA = a->strideA; p.strideB = a->strideB; p.strideA2 = a->strideA2; p.strideB2 = a->strideB2;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(((a->N + 127) / 128) * ((a->Kc + 127) / 128), splits, Z);
+  dim3 grid(((a->N + pl.nsa * 128 - 1) / (pl.nsa * 128)) * ((a->Kc + pl.nsb * 128 - 1) / (pl.nsb * 128)), splits, Z);
   const long long total = (long long)Z * a->N * a->Kc;
   const long long ldo_n = a->ldo_n > 0 ? a->ldo_n : (long long)a->taps * a->Kc;
   const long long ldo_t = a->ldo_t > 0 ? a->ldo_t : a->Kc;
   const long long ldo_b = a->ldo_b > 0 ? a->ldo_b : (long long)a->N * a->taps * a->Kc;
   p.out = a->out; p.ldo_b = ldo_b; p.ldo_n = ldo_n; p.ldo_t = ldo_t; p.scale = a->scale; p.accumulate = a->accumulate;
-  if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  if (a->dtype == DFW_BF16) launch_tn<__bf16>(p, pl, grid, st);
+  else launch_tn<_Float16>(p, pl, grid, st);
   DFW_CHECK_LAUNCH();
   if (splits == 1) return 0;
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, st, (const float*)p.slab, a->out, splits, Z,
