@@ -389,20 +389,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* x, float* part,
   }
 }
 
-// block = 64 columns x 4 lanes over the chunks (fixed order inside a lane, fixed 4-way combine)
+// block = 16 columns x 16 lanes over the chunks (fixed order inside a lane, fixed pairwise combine): N / 16 workgroups, so
+// a 320-column bias gradient folds its 512 partial rows on 20 CUs with 32 loads per thread (the 64 x 4 layout ran it on 5
+// workgroups with 128 serial loads each: 12.8 us per call, 2.4 ms per training step)
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* part, float* out, int chunks, int N, int segs,
                                                           long long ldo, float scale, int accumulate) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl, seg = blockIdx.y;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, l16 = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cl, seg = blockIdx.y;
   float a = 0.f;
   if (n < N)
-    for (int c = lane4; c < chunks; c += 4) a += part[((size_t)seg * chunks + c) * N + n];
-  red[lane4][cl] = a;
+    for (int c = l16; c < chunks; c += 16) a += part[((size_t)seg * chunks + c) * N + n];
+  red[l16][cl] = a;
   __syncthreads();
-  if (lane4 == 0 && n < N) {
+  if (l16 == 0 && n < N) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = red[r][cl];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int r = 0; r < w; ++r) t[r] += t[r + w];
     float* o = out + (size_t)seg * ldo + n;
-    *o = (accumulate ? *o : 0.f) + scale * ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+    *o = (accumulate ? *o : 0.f) + scale * t[0];
   }
 }
 
@@ -836,7 +845,15 @@ __global__ __launch_bounds__(64) void fold_scalar_kernel(const float* part, floa
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* part, long long n) {
   __shared__ float red[4];
   float acc = 0.f;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) acc += x[e] * x[e];
+  const long long n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;     // 16-byte loads, four partial sums
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)x)[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] += v[i] * v[i];
+  }
+  acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  for (long long e = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) acc += x[e] * x[e];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -1067,7 +1084,7 @@ extern "C" int dfw_colsum(const void* x, float* out, void* workspace, size_t wor
   if (dtype == DFW_BF16) hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, dim3(256), 0, st, (const char*)x, (float*)workspace, (int)rows_per_seg, N, ldx, rpc);
   else hipLaunchKernelGGL((colsum_kernel<_Float16>), grid, dim3(256), 0, st, (const char*)x, (float*)workspace, (int)rows_per_seg, N, ldx, rpc);
   DFW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64, segs), dim3(256), 0, st, (const float*)workspace, out,
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16, segs), dim3(256), 0, st, (const float*)workspace, out,
                      chunks, N, segs, (long long)(ldo > 0 ? ldo : N), scale, accumulate);
   DFW_CHECK_LAUNCH();
   return 0;
