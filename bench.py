@@ -416,7 +416,8 @@ def main():
                                      peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                      frac=round(afl / at / 1e12 / MFMA_PEAK_TFLOPS, 4), launches_per_step=an,
                                      ms_per_step=round(at * 1e3, 3),
-                                     mfma_util=pmc.get("fsa_ring_kernel", {}).get("mfma_util"))
+                                     mfma_util=max([v.get("mfma_util") or 0.0 for k, v in pmc.items() if k.startswith("fsa_ring_kernel")],
+                                                   default=None))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -107,6 +107,15 @@ class XattnBwdArgs(C.Structure):
                 ("scale", _f32), ("dtype", _i32)]
 
 
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("out", _vp), ("dout", _vp), ("lse", _vp), ("delta", _vp),
+                ("dq", _vp), ("dk", _vp), ("dv", _vp),
+                ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32),
+                ("ldq", _i32), ("ldkv", _i32), ("ldo", _i32), ("lddq", _i32), ("lddkv", _i32),
+                ("q_bs", _i64), ("kv_bs", _i64), ("o_bs", _i64), ("dq_bs", _i64), ("dkv_bs", _i64),
+                ("scale", _f32), ("dtype", _i32)]
+
+
 class AdamWArgs(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_sumsq", _vp), ("n", _i64),
                 ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_grad_norm", _f32),
@@ -150,6 +159,7 @@ SYMBOLS = {
     "dfw_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_fsa_attention_bwd": (_i32, [C.POINTER(FsaBwdArgs), _vp]),
+    "dfw_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
     "dfw_cross_attention_bwd": (_i32, [C.POINTER(XattnBwdArgs), _vp]),
     "dfw_cross_attention_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dfw_silu": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -26,9 +26,15 @@ struct FsaBwdP {
   char* dq; char* dk; char* dv;
   uint32_t qkv_bytes, do_bytes, dqkv_bytes;
   int batch, heads, n, nshot, n_plain;
-  int ld, ldo, ldd;                       // token strides of q/k/v (one fused buffer), dout, dq/dk/dv
+  int ld, ldo, ldd;                       // token strides of q, dout, dq
   long long bs, obs, dbs;                 // image strides
   float scale;
+  // keys / values: n_kv rows per image at token stride ldkv, image stride kvbs, addressed from p.k (v = k + voff bytes
+  // inside the same buffer of kv_bytes); their gradients at lddkv / dkvbs from p.dk / p.dv.  Self-attention over the fused
+  // qkv buffer: n_kv = n, ldkv = ld, kvbs = bs, lddkv = ldd, dkvbs = dbs.  Cross-attention: its own K/V tensors.
+  int n_kv, ldkv, lddkv;
+  long long kvbs, dkvbs;
+  uint32_t kv_bytes, voff;
 };
 
 __device__ __forceinline__ uint32_t row_off(int row, int chunk) {   // K-style image: b128 row reads
@@ -72,9 +78,10 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int bank_b = b - p.n_plain;
-  const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);        // q, k, v live in one fused buffer
+  const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);
+  const __amdgpu_buffer_rsrc_t rkv = make_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.dout, p.do_bytes);
-  const uint32_t koff = (uint32_t)((const char*)p.k - (const char*)p.q), voff = (uint32_t)((const char*)p.v - (const char*)p.q);
+  const uint32_t voff = p.voff;
 
   const int qrow = q0 + lr;
   const bool qok = qrow < p.n;
@@ -93,20 +100,20 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
   const float ndelta = qok ? -p.delta[stat] : 0.f;
 
   const int srow0 = tid >> 3, sc = tid & 7;
-  const int tiles_own = (p.n + KT - 1) / KT;
+  const int tiles_own = (p.n_kv + KT - 1) / KT;
   const int tiles_bank = (p.nshot > 0 && bank_b >= 0) ? tiles_own : 0;
   const int ntiles = tiles_own + (tiles_bank ? p.nshot * tiles_bank : 0);
   i32x4 gk[2], gv[2];
   auto issue = [&](int t) {
     int img = b, tt = t;
     if (t >= tiles_own) { img = bank_b * p.nshot + (t - tiles_own) / tiles_bank; tt = (t - tiles_own) % tiles_bank; }
-    const size_t base = (size_t)img * p.bs + head * 64 + sc * 8;
+    const size_t base = (size_t)img * p.kvbs + head * 64 + sc * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = tt * KT + srow0 + 32 * i;
-      const uint32_t o = key < p.n ? (uint32_t)((base + (size_t)key * p.ld) * sizeof(T)) : kOOB;
-      gk[i] = buf_load16(rqkv, o == kOOB ? kOOB : o + koff);
-      gv[i] = buf_load16(rqkv, o == kOOB ? kOOB : o + voff);
+      const uint32_t o = key < p.n_kv ? (uint32_t)((base + (size_t)key * p.ldkv) * sizeof(T)) : kOOB;
+      gk[i] = buf_load16(rkv, o);
+      gv[i] = buf_load16(rkv, o == kOOB ? kOOB : o + voff);
     }
   };
   auto write_lds = [&](char* buf) {
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
     const char* vbuf = kbuf + 2 * TILE;
     int tt = t;
     if (t >= tiles_own) tt = (t - tiles_own) % tiles_bank;
-    const int nvalid = p.n - tt * KT;
+    const int nvalid = p.n_kv - tt * KT;
     // S^T = K Q^T - lse ;  dP^T = V dO^T - delta   (row constants as initial accumulators)
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -210,18 +217,19 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
   const int lr = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, kimg = blockIdx.z;
   const int key = blockIdx.x * 128 + wave * 32 + lr;      // the key this lane owns (column of S)
-  const bool kok = key < p.n;
+  const bool kok = key < p.n_kv;
   const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);
+  const __amdgpu_buffer_rsrc_t rkv = make_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.dout, p.do_bytes);
-  const uint32_t koff = (uint32_t)((const char*)p.k - (const char*)p.q), voff = (uint32_t)((const char*)p.v - (const char*)p.q);
+  const uint32_t voff = p.voff;
   // B operands: lane holds K[key][16 s + 8 lh + 0..7] (= K^T[k = d][col = key]), same for V
   typename Tr<T>::v8 kf[4], vf[4];
   {
-    const uint32_t base = kok ? (uint32_t)(((size_t)kimg * p.bs + (size_t)key * p.ld + head * 64 + lh * 8) * sizeof(T)) : kOOB;
+    const uint32_t base = kok ? (uint32_t)(((size_t)kimg * p.kvbs + (size_t)key * p.ldkv + head * 64 + lh * 8) * sizeof(T)) : kOOB;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kf[s] = as_v8<T>(buf_load16(rqkv, base == kOOB ? kOOB : base + koff + (uint32_t)(s * 32)));
-      vf[s] = as_v8<T>(buf_load16(rqkv, base == kOOB ? kOOB : base + voff + (uint32_t)(s * 32)));
+      kf[s] = as_v8<T>(buf_load16(rkv, base == kOOB ? kOOB : base + (uint32_t)(s * 32)));
+      vf[s] = as_v8<T>(buf_load16(rkv, base == kOOB ? kOOB : base + voff + (uint32_t)(s * 32)));
     }
   }
   // query sources: the image's own rows, plus (support image of a lock-step batch) its episode's query image
@@ -326,8 +334,8 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
   }
   if (kok) {
     // D layout of dK^T / dV^T: col = key (this lane), rows d = (r & 3) + 8 (r >> 2) + 4 lh of the 32-d block
-    char* kb = p.dk + ((size_t)kimg * p.dbs + (size_t)key * p.ldd + head * 64) * sizeof(T);
-    char* vb = p.dv + ((size_t)kimg * p.dbs + (size_t)key * p.ldd + head * 64) * sizeof(T);
+    char* kb = p.dk + ((size_t)kimg * p.dkvbs + (size_t)key * p.lddkv + head * 64) * sizeof(T);
+    char* vb = p.dv + ((size_t)kimg * p.dkvbs + (size_t)key * p.lddkv + head * 64) * sizeof(T);
     const float ln2 = 0.6931471805599453f;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -595,12 +603,62 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
   p.ld = a->ld; p.ldo = a->ldo; p.ldd = a->ldd;
   p.bs = (long long)a->n * a->ld; p.obs = (long long)a->n * a->ldo; p.dbs = (long long)a->n * a->ldd;
   p.scale = a->scale;
+  p.n_kv = a->n; p.ldkv = a->ld; p.lddkv = a->ldd; p.kvbs = p.bs; p.dkvbs = p.dbs;
+  p.kv_bytes = p.qkv_bytes - (uint32_t)(C * es); p.voff = (uint32_t)(C * es);
   dim3 grid((a->n + 127) / 128, a->heads, a->batch);
   if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), grid, dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
   if (bf) hipLaunchKernelGGL((fsa_bwd_dkv_kernel<__bf16>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fsa_bwd_dkv_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+// General form: queries and keys / values in their own tensors (attn2 of the training step on the MFMA path: the 77 prompt
+// tokens are two 64-key tiles, the ragged one masked).  Same kernels, same conventions (q pre-scaled, lse from the forward).
+extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->out || !a->dout || !a->lse || !a->delta || !a->dq || !a->dk || !a->dv) return DFW_EINVAL;
+  if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kv <= 0) return DFW_EINVAL;
+  if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
+  const int C = a->heads * 64;
+  if ((a->ldq | a->ldkv | a->ldo | a->lddq | a->lddkv) % 8 != 0) return DFW_ESHAPE;
+  if (a->ldq < C || a->ldkv < C || a->ldo < C || a->lddq < C || a->lddkv < C) return DFW_ESHAPE;
+  const char* kc = (const char*)a->k;
+  const char* vc = (const char*)a->v;
+  if (vc < kc || ((vc - kc) & 15)) return DFW_ESHAPE;        // v rides in k's buffer descriptor at a 16-byte-aligned offset
+  const size_t es = 2;
+  auto extent = [&](int64_t bs, int n, int ld) { return (int64_t)(a->batch - 1) * bs + (int64_t)(n - 1) * ld + C; };
+  const int64_t qe = extent(a->q_bs, a->n_q, a->ldq), oe = extent(a->o_bs, a->n_q, a->ldo);
+  const int64_t ke = extent(a->kv_bs, a->n_kv, a->ldkv) + (int64_t)((vc - kc) / es);
+  if (qe >= (1ll << 30) || oe >= (1ll << 30) || ke >= (1ll << 30)) return DFW_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = a->dtype == DFW_BF16;
+  {
+    const long long total = (long long)a->batch * a->heads * a->n_q;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
+    else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
+    DFW_CHECK_LAUNCH();
+  }
+  FsaBwdP p;
+  p.q = (const char*)a->q; p.k = kc; p.v = vc;
+  p.dout = (const char*)a->dout; p.lse = a->lse; p.delta = a->delta;
+  p.dq = (char*)a->dq; p.dk = (char*)a->dk; p.dv = (char*)a->dv;
+  p.qkv_bytes = (uint32_t)(qe * es); p.do_bytes = (uint32_t)(oe * es); p.dqkv_bytes = 0;
+  p.batch = a->batch; p.heads = a->heads; p.n = a->n_q; p.nshot = 0; p.n_plain = a->batch;
+  p.ld = a->ldq; p.ldo = a->ldo; p.ldd = a->lddq;
+  p.bs = a->q_bs; p.obs = a->o_bs; p.dbs = a->dq_bs;
+  p.scale = a->scale;
+  p.n_kv = a->n_kv; p.ldkv = a->ldkv; p.lddkv = a->lddkv; p.kvbs = a->kv_bs; p.dkvbs = a->dkv_bs;
+  p.kv_bytes = (uint32_t)(ke * es); p.voff = (uint32_t)(vc - kc);
+  dim3 gq((a->n_q + 127) / 128, a->heads, a->batch), gk((a->n_kv + 127) / 128, a->heads, a->batch);
+  if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), gq, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), gq, dim3(256), 0, st, p);
+  DFW_CHECK_LAUNCH();
+  if (bf) hipLaunchKernelGGL((fsa_bwd_dkv_kernel<__bf16>), gk, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fsa_bwd_dkv_kernel<_Float16>), gk, dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
   return 0;
 }

@@ -211,6 +211,33 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     return dqkv
 
 
+def attention_bwd(q, k, v, out, dout, lse, heads, dk_out, dv_out, scale=None):
+    """Flash backward with queries and keys / values in their own tensors (attn2 on the MFMA path).  q [B, N, heads*64]
+    PRE-SCALED (linear(..., colscale=(C, FSA_QSCALE))); k / v [B, L, heads*64] column slices of one buffer; out / dout
+    [B, N, heads*64] contiguous; lse [B, heads, N] from fsa_attention(..., lse=); dk_out / dv_out: views that receive
+    dK / dV.  -> dq [B, N, heads*64] with respect to the unscaled projection output."""
+    B, N, Cq = q.shape
+    Lc = k.shape[1]
+    assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1) and v.data_ptr() >= k.data_ptr()
+    assert out.shape == (B, N, Cq) and dout.shape == out.shape and out.is_contiguous() and dout.is_contiguous()
+    assert lse.shape == (B, heads, N) and lse.dtype == torch.float32 and lse.is_contiguous()
+    assert dk_out.shape == (B, Lc, Cq) and dv_out.shape == dk_out.shape and dk_out.stride(2) == 1
+    assert dk_out.stride(0) == dv_out.stride(0) and dk_out.stride(1) == dv_out.stride(1)
+    dq = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
+    delta = torch.empty(B, heads, N, dtype=torch.float32, device=q.device)
+    a = L.AttnBwdArgs()
+    a.q, a.k, a.v, a.out, a.dout, a.lse, a.delta = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk_out.data_ptr(), dv_out.data_ptr()
+    a.batch, a.heads, a.n_q, a.n_kv = B, heads, N, Lc
+    a.ldq, a.ldkv, a.ldo, a.lddq, a.lddkv = q.stride(1), k.stride(1), Cq, Cq, dk_out.stride(1)
+    a.q_bs, a.kv_bs, a.o_bs, a.dq_bs, a.dkv_bs = q.stride(0), k.stride(0), N * Cq, N * Cq, dk_out.stride(0)
+    a.scale = scale if scale is not None else 64 ** -0.5
+    a.dtype = _dt(q)
+    L.check(L.lib().dfw_attention_bwd(C.byref(a), _stream()), "dfw_attention_bwd")
+    return dq
+
+
 def cross_attention_bwd(q, k, v, dout, heads, dk_out, dv_out, scale=None):
     """attn2 backward.  q / dout [B, N, heads*64]; k / v [B, L, heads*64] views; dk_out / dv_out: [B, L, heads*64]
     views (column slices of the fused prompt-K/V gradient buffer) that receive dK / dV.  -> dq [B, N, heads*64]."""

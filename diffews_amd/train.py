@@ -421,15 +421,20 @@ class UNetTrainer:
         tape.add(att, att_bwd)
         t1 = self._linear(tape, att.view(-1, C), b + "attn1.to_out.0.weight", b + "attn1.to_out.0.bias", residual=t0)
         l2 = self._ln(tape, t1, b + "norm2.weight", b + "norm2.bias")
-        q2 = self._linear(tape, l2, b + "attn2.to_q.weight")
+        # attn2 on the MFMA path: the prompt's 77 keys are two 64-key tiles of the flash kernels (ragged one masked); q
+        # leaves to_q pre-scaled like attn1's.  (dfw_cross_attention / _bwd, the VALU kernels of the folded-prompt
+        # inference path, took 6.7 ms of the 7-shot step here.)
+        q2 = self._linear(tape, l2, b + "attn2.to_q.weight", colscale=(C, ops.FSA_QSCALE))
         o, _ = t["kvslice"]
         kv2 = kv_all.view(B, L_ctx, -1)[..., o:o + 2 * C]
         q2v = q2.view(B, N, C)
-        ca = ops.cross_attention(q2v, kv2[..., :C], kv2[..., C:], heads)
+        lse2 = torch.empty(B, heads, N, dtype=torch.float32, device=x.device)
+        ca = ops.fsa_attention(q2v, kv2[..., :C], kv2[..., C:], heads, q_prescaled=True, lse=lse2)
 
         def ca_bwd(dca):
             dkv = dkv_all.view(B, L_ctx, -1)[..., o:o + 2 * C]
-            tape.accum(q2, ob.cross_attention_bwd(q2v, kv2[..., :C], kv2[..., C:], dca, heads, dkv[..., :C], dkv[..., C:]).view(-1, C))
+            tape.accum(q2, ob.attention_bwd(q2v, kv2[..., :C], kv2[..., C:], ca, dca.contiguous(), lse2, heads,
+                                            dkv[..., :C], dkv[..., C:]).view(-1, C))
         tape.add(ca, ca_bwd)
         t2 = self._linear(tape, ca.view(-1, C), b + "attn2.to_out.0.weight", b + "attn2.to_out.0.bias", residual=t1)
         l3 = self._ln(tape, t2, b + "norm3.weight", b + "norm3.bias")

@@ -404,6 +404,23 @@ typedef struct {
 
 int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream);
 
+/* The same backward with queries and keys / values in their own tensors (attn2 of the training step, T:1368-1375, on
+ * the MFMA path: forward = dfw_fsa_attention with n_kv = 77 prompt tokens and lse requested).  q [batch][n_q][heads*64]
+ * PRE-SCALED as above; k / v [batch][n_kv][heads*64] column slices of ONE buffer (v >= k, same strides); out / dout share
+ * strides; lse / delta fp32 [batch][heads][n_q] (delta is scratch).  dq with respect to the unscaled projection output;
+ * dk / dv share strides.  Strides in elements.  Deterministic: no cross-workgroup sums. */
+typedef struct {
+  const void* q; const void* k; const void* v; const void* out; const void* dout; const float* lse; float* delta;
+  void* dq; void* dk; void* dv;
+  int32_t batch, heads, n_q, n_kv;
+  int32_t ldq, ldkv, ldo, lddq, lddkv;
+  int64_t q_bs, kv_bs, o_bs, dq_bs, dkv_bs;
+  float scale;
+  int32_t dtype;
+} dfw_attn_bwd_args;
+
+int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream);
+
 /* Cross-attention (attn2) backward over a short context; same tensor conventions as dfw_cross_attention.
  * dq [batch][n_q][heads*64] (strides lddq / dq_bs); dk / dv [batch][L][heads*64] at row stride lddkv, image stride
  * dkv_bs (column slices of the fused prompt K/V gradient buffer).  workspace: dfw_cross_attention_bwd_workspace_bytes. */

@@ -338,6 +338,36 @@ def test_training_loop_loss_decreases_and_matches_torch_adamw(hip_lib):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Bn,heads,N,Lc", [(2, 2, 256, 77), (1, 1, 100, 2), (3, 4, 64, 77), (2, 5, 1000, 130), (1, 2, 4096, 77)])
+def test_attention_backward_separate_kv(B, dtype, Bn, heads, N, Lc):
+    """attn2 of the training step on the MFMA path: flash forward (n_kv = 77 prompt tokens, ragged second tile) with the
+    row log-sum-exp + dfw_attention_bwd (queries and keys / values in their own tensors) vs torch autograd of SDPA; K | V
+    and dK | dV are column slices of wider rows, as the fused prompt-K/V buffers of all 16 layers are laid out."""
+    ops, ob = B
+    from diffews_amd.ops import FSA_QSCALE
+    C = heads * 64
+    q = (rnd((Bn, N, C), dtype, 1).float() * FSA_QSCALE * 2).to(dtype)          # pre-scaled q
+    dout = rnd((Bn, N, C), dtype, 2)
+    kv = rnd((Bn, Lc, 2 * C + 64), dtype, 3)
+    qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
+    sh = lambda t: t.reshape(Bn, -1, heads, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(sh(qr / FSA_QSCALE * 64 ** -0.5), sh(kvr[..., :C]), sh(kvr[..., C:2 * C]),
+                                       scale=1.0).transpose(1, 2).reshape(Bn, N, C)
+    o.backward(dout.float())
+    want_dq = qr.grad * FSA_QSCALE      # autograd's gradient is w.r.t. the pre-scaled q; the kernel returns d(unscaled)
+    qg, kvg = q.cuda(), kv.cuda()
+    lse = torch.empty(Bn, heads, N, dtype=torch.float32, device="cuda")
+    out = ops.fsa_attention(qg, kvg[..., :C], kvg[..., C:2 * C], heads, q_prescaled=True, lse=lse)
+    assert rel(out, o.detach()) < 1.5 * TOL[dtype]
+    dkv = torch.zeros_like(kvg)
+    dq = ob.attention_bwd(qg, kvg[..., :C], kvg[..., C:2 * C], out, dout.cuda(), lse, heads, dkv[..., :C], dkv[..., C:2 * C])
+    assert rel(dq, want_dq) < 2 * TOL[dtype], "dq"
+    assert rel(dkv[..., :C], kvr.grad[..., :C]) < 2 * TOL[dtype], "dk"
+    assert rel(dkv[..., C:2 * C], kvr.grad[..., C:2 * C]) < 2 * TOL[dtype], "dv"
+    assert float(dkv[..., 2 * C:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Bn,heads,N,Lc", [(2, 2, 256, 77), (1, 1, 100, 2), (3, 4, 64, 77)])
 def test_cross_attention_backward(B, dtype, Bn, heads, N, Lc):
     """attn2 backward (77-token prompt in training, T:1368; 2 tokens at inference) vs torch autograd of SDPA; dk / dv are

@@ -47,7 +47,7 @@ def test_struct_layouts_match_header():
                        ("dfw_conv_small_args", _lib.ConvSmallArgs), ("dfw_gemm_tn_args", _lib.GemmTnArgs),
                        ("dfw_groupnorm_bwd_args", _lib.GroupNormBwdArgs), ("dfw_layernorm_bwd_args", _lib.LayerNormBwdArgs),
                        ("dfw_fsa_bwd_args", _lib.FsaBwdArgs), ("dfw_xattn_bwd_args", _lib.XattnBwdArgs),
-                       ("dfw_adamw_args", _lib.AdamWArgs), ("dfw_image_args", _lib.ImageArgs)):
+                       ("dfw_attn_bwd_args", _lib.AttnBwdArgs), ("dfw_adamw_args", _lib.AdamWArgs), ("dfw_image_args", _lib.ImageArgs)):
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", hdr).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -65,7 +65,7 @@ def test_sizeof_structs_against_compiler(tmp_path):
     src = tmp_path / "sz.c"
     names = ["dfw_gemm_args", "dfw_fsa_args", "dfw_xattn_args", "dfw_groupnorm_args", "dfw_layernorm_args",
              "dfw_conv_small_args", "dfw_gemm_tn_args", "dfw_groupnorm_bwd_args", "dfw_layernorm_bwd_args",
-             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_adamw_args", "dfw_image_args"]
+             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_attn_bwd_args", "dfw_adamw_args", "dfw_image_args"]
     src.write_text('#include <stdio.h>\n#include "diffews_hip.h"\nint main(){' +
                    "".join(f'printf("%zu ", sizeof({n}));' for n in names) + 'return 0;}\n')
     exe = tmp_path / "sz"
@@ -74,7 +74,7 @@ def test_sizeof_structs_against_compiler(tmp_path):
     assert sizes == [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.FsaArgs, _lib.XattnArgs, _lib.GroupNormArgs,
                                                 _lib.LayerNormArgs, _lib.ConvSmallArgs, _lib.GemmTnArgs,
                                                 _lib.GroupNormBwdArgs, _lib.LayerNormBwdArgs, _lib.FsaBwdArgs,
-                                                _lib.XattnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs)]
+                                                _lib.XattnBwdArgs, _lib.AttnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs)]
 
 
 def test_product_never_imports_oracle():
