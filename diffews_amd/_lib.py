@@ -166,6 +166,7 @@ SYMBOLS = {
     "dfw_sumsq": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "dfw_adamw": (_i32, [C.POINTER(AdamWArgs), _vp]),
     "dfw_weight_relayout": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp]),
+    "dfw_weight_relayout_batch": (_i32, [_vp, _i32, _i64, _vp]),
     "dfw_resample_ksize": (_i32, [_i32, _i32]),
     "dfw_resample_coeffs": (_i32, [_i32, _i32, _vp, _vp]),
     "dfw_image_to_tensor": (_i32, [C.POINTER(ImageArgs), _vp]),

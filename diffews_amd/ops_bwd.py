@@ -297,6 +297,30 @@ def conv3x3_wd(w, cout):
     return y
 
 
+def relayout_table(entries, device):
+    """entries: [(kind, w, y)] with kind 'T' (Linear W [N, K] -> y [K, N]) or 'D' (packed conv W [Cout, 9*Cin] ->
+    y [Cin, 9*Cout], taps mirrored).  -> (device int64 table [n, 12], n, total_blocks) for weight_relayout_batch: the
+    tensors' addresses are baked in, so the table is valid while they live."""
+    rows, blk = [], 0
+    for kind, w, y in entries:
+        assert w.is_contiguous() and y.is_contiguous() and w.dtype == y.dtype
+        if kind == "T":
+            N, K = w.shape
+            R, Cc, ldx, ldy, nb, x_bs, y_bs, flip = N, K, K, N, 1, 0, 0, 0
+        else:
+            cout, cin = w.shape[0], w.shape[1] // 9
+            R, Cc, ldx, ldy, nb, x_bs, y_bs, flip = cout, cin, 9 * cin, 9 * cout, 9, cin, cout, 1
+        assert R % 8 == 0 and Cc % 8 == 0 and w.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+        rows.append([w.data_ptr(), y.data_ptr(), R, Cc, ldx, ldy, x_bs, y_bs, nb, flip, blk, 0])
+        blk += ((Cc + 63) // 64) * ((R + 63) // 64) * nb
+    return torch.tensor(rows, dtype=torch.int64).to(device), len(rows), blk
+
+
+def weight_relayout_batch(table):
+    t, n, blocks = table
+    L.check(L.lib().dfw_weight_relayout_batch(t.data_ptr(), n, blocks, _stream()), "dfw_weight_relayout_batch")
+
+
 def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_sumsq=None,
           max_grad_norm=0.0, shadow=None):
     for t in (param, grad, exp_avg, exp_avg_sq):

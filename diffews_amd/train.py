@@ -97,6 +97,29 @@ class ParamStore:
     def g(self, name):
         return self._view(self.grad, name)
 
+    # First-touch gradient writes: a step that starts from zero gradients does not memset the 3.5 GB flat buffer; the first
+    # kernel that writes a parameter's gradient stores (accumulate = 0), later ones add.  The alignment pads between
+    # entries are never written and keep their zeros; entries nobody touched are zeroed at the end of the step.
+    def begin_step(self, fresh):
+        self._touched = set() if fresh else None
+
+    def acc(self, *names):
+        """accumulate flag for a kernel about to write these gradients (all or none must have been written before)."""
+        if getattr(self, "_touched", None) is None:
+            return True
+        seen = [n in self._touched for n in names]
+        assert all(seen) or not any(seen), names
+        self._touched.update(names)
+        return seen[0]
+
+    def finish_step(self):
+        if getattr(self, "_touched", None) is None:
+            return
+        for name in self.spec:
+            if name not in self._touched:
+                self.g(name).zero_()
+        self._touched = None
+
     def sync_shadow(self):
         self.shadow.copy_(self.master)
         self.version += 1
@@ -117,7 +140,7 @@ class UNetTrainer:
         self.loss_scale = float(loss_scale)
         self.training = True
         self.step_count = 0
-        self._derived, self._derived_version = {}, -1
+        self._derived, self._derived_version, self._derived_table = {}, -1, None
         self._build(state_dict)
 
     # ------------------------------------------------------------------ parameters
@@ -313,12 +336,23 @@ class UNetTrainer:
         """16-bit copies the data-gradient GEMMs read: 'T' = W^T of a Linear ([K, N] as the forward kernel's [N'][K']),
         'D' = tap-mirrored, channel-swapped conv3x3 weight.  Rebuilt lazily after every optimizer step."""
         if self._derived_version != self.P.version:
-            self._derived, self._derived_version = {}, self.P.version
+            if self._derived_table is not None:
+                ob.weight_relayout_batch(self._derived_table)      # one launch rewrites every copy in place
+            else:
+                self._derived = {}
+            self._derived_version = self.P.version
         key = (kind, name)
-        if key not in self._derived:
+        if key not in self._derived:                               # first step (or a new consumer): build lazily
             w = self.P.w(name)
             self._derived[key] = ob.linear_wt(w) if kind == "T" else ob.conv3x3_wd(w, w.shape[0])
+            self._derived_table = None
         return self._derived[key]
+
+    def _freeze_derived(self):
+        """After a backward: the set of derived copies is known -- refresh them with one batched launch from now on."""
+        if self._derived_table is None and self._derived:
+            entries = [(kind, self.P.w(name), y) for (kind, name), y in self._derived.items()]
+            self._derived_table = ob.relayout_table(entries, self.device)
 
     # ------------------------------------------------------------------ ops with registered backward
     def _linear(self, tape, x, wname, bname=None, residual=None, colscale=None, need_dx=True):
@@ -327,9 +361,9 @@ class UNetTrainer:
 
         def bwd(dy):
             N, K = P.spec[wname][1]
-            ob.gemm_tn(dy, x, out=P.g(wname).view(1, N, 1, K), accumulate=True, scale=gs)
+            ob.gemm_tn(dy, x, out=P.g(wname).view(1, N, 1, K), accumulate=P.acc(wname), scale=gs)
             if bname:
-                ob.colsum(dy, out=P.g(bname).view(1, N), accumulate=True, scale=gs)
+                ob.colsum(dy, out=P.g(bname).view(1, N), accumulate=P.acc(bname), scale=gs)
             if need_dx:
                 tape.accum(x, ops.linear(dy, self._d("T", wname)))
             if residual is not None:
@@ -347,8 +381,8 @@ class UNetTrainer:
 
         def bwd(dy):
             ob.gemm_tn(dy, x, taps=9, geom=(Hi, Wi, Ho, Wo, stride, 1, int(ups)), out=P.g(wname).view(1, cout, 9, Cin),
-                       accumulate=True, scale=gs)
-            ob.colsum(dy, out=P.g(bname).view(1, cout), accumulate=True, scale=gs)
+                       accumulate=P.acc(wname), scale=gs)
+            ob.colsum(dy, out=P.g(bname).view(1, cout), accumulate=P.acc(bname), scale=gs)
             if tslice is not None:      # d(time_emb_proj output)[img] = sum over the image's pixels (kept at loss scale)
                 o, c = tslice
                 ob.colsum(dy, segs=B, out=dtproj[:, o:o + c])
@@ -372,7 +406,7 @@ class UNetTrainer:
 
         def bwd(dy):
             tape.accum(x, ob.groupnorm_bwd(x, dy, mr, P.p(gname), P.p(bname), self.groups, silu, P.g(gname), P.g(bname),
-                                           accumulate=True, grad_scale=gs))
+                                           accumulate=P.acc(gname, bname), grad_scale=gs))
         tape.add(y, bwd)
         return y
 
@@ -381,7 +415,7 @@ class UNetTrainer:
         y = ops.layernorm(x, P.p(gname), P.p(bname))
 
         def bwd(dy):
-            tape.accum(x, ob.layernorm_bwd(x, dy, P.p(gname), P.g(gname), P.g(bname), accumulate=True, grad_scale=gs))
+            tape.accum(x, ob.layernorm_bwd(x, dy, P.p(gname), P.g(gname), P.g(bname), accumulate=P.acc(gname, bname), grad_scale=gs))
         tape.add(y, bwd)
         return y
 
@@ -454,8 +488,7 @@ class UNetTrainer:
         P, dt, dev, cfg = self.P, self.dtype, self.device, self.config
         tape = _Tape()
         gs = 1.0 / self.loss_scale
-        if zero_grad:
-            P.grad.zero_()
+        P.begin_step(fresh=zero_grad)
         zr = z_refcat.to(dev, torch.float32).contiguous()
         zq = z_tag.to(dev, torch.float32).contiguous()
         n_ref, bq = zr.shape[0], zq.shape[0]
@@ -476,8 +509,8 @@ class UNetTrainer:
         def tproj_bwd(_):
             # every resnet has written its column slice of dtproj by now (they sit later on the tape)
             d16 = ob.nchw_to_nhwc(dtproj.view(Bt, self.tp_total, 1, 1), dt, cp=self.tp_total).view(Bt, self.tp_total)
-            ob.gemm_tn(d16, a2, out=P.g("tp_w").view(1, self.tp_total, 1, a2.shape[1]), accumulate=True, scale=gs)
-            ob.colsum(d16, out=P.g("tp_b").view(1, self.tp_total), accumulate=True, scale=gs)
+            ob.gemm_tn(d16, a2, out=P.g("tp_w").view(1, self.tp_total, 1, a2.shape[1]), accumulate=P.acc("tp_w"), scale=gs)
+            ob.colsum(d16, out=P.g("tp_b").view(1, self.tp_total), accumulate=P.acc("tp_b"), scale=gs)
             tape.accum(a2, ops.linear(d16, self._d("T", "tp_w")))
         tape.add(tproj, tproj_bwd)
         # ---- prompt K/V of all layers in one GEMM
@@ -489,7 +522,7 @@ class UNetTrainer:
         kv_all = ops.linear(ehs2d, P.w("kv_w_all"))
         dkv_all = torch.zeros_like(kv_all)                                                   # filled by the attn2 closures
         tape.add(kv_all, lambda _: ob.gemm_tn(dkv_all, ehs2d, out=P.g("kv_w_all").view(1, self.kv_total, 1, ehs2d.shape[1]),
-                                              accumulate=True, scale=gs))
+                                              accumulate=P.acc("kv_w_all"), scale=gs))
         # ---- conv_in_ref | conv_in (U:1117-1121)
         h, w = zq.shape[2:]
         x = torch.empty(Bt, h, w, c0, dtype=dt, device=dev)
@@ -501,12 +534,15 @@ class UNetTrainer:
             geom = (h, w, h, w, 1, 1, 0)
             if n_ref:
                 zin = ob.nchw_to_nhwc(zr, dt, cp=8)
-                ob.gemm_tn(dx[:n_ref], zin, taps=9, geom=geom, out=P.g("conv_in_ref.weight").view(1, c0, 9, 8), accumulate=True, scale=gs)
-                ob.colsum(dx[:n_ref], out=P.g("conv_in_ref.bias").view(1, c0), accumulate=True, scale=gs)
+                ob.gemm_tn(dx[:n_ref], zin, taps=9, geom=geom, out=P.g("conv_in_ref.weight").view(1, c0, 9, 8), accumulate=P.acc("conv_in_ref.weight"), scale=gs)
+                ob.colsum(dx[:n_ref], out=P.g("conv_in_ref.bias").view(1, c0), accumulate=P.acc("conv_in_ref.bias"), scale=gs)
             zin = ob.nchw_to_nhwc(zq, dt, cp=8)
             g8 = ob.gemm_tn(dx[n_ref:], zin, taps=9, geom=geom, scale=gs)                  # [1, c0, 9, 8]: 4 real input channels
-            P.g("conv_in.weight").add_(g8.view(c0, 9, 8)[..., :cfg["in_channels"]])
-            ob.colsum(dx[n_ref:], out=P.g("conv_in.bias").view(1, c0), accumulate=True, scale=gs)
+            if P.acc("conv_in.weight"):
+                P.g("conv_in.weight").add_(g8.view(c0, 9, 8)[..., :cfg["in_channels"]])
+            else:
+                P.g("conv_in.weight").copy_(g8.view(c0, 9, 8)[..., :cfg["in_channels"]])
+            ob.colsum(dx[n_ref:], out=P.g("conv_in.bias").view(1, c0), accumulate=P.acc("conv_in.bias"), scale=gs)
         tape.add(x, conv_in_bwd)
         # ---- trunk (U:1153-1243)
         lpb, nb = cfg["layers_per_block"], len(cfg["block_out_channels"])
@@ -549,13 +585,15 @@ class UNetTrainer:
         dpn = torch.zeros(Bt, oc, h, w, dtype=torch.float32, device=dev)
         loss, _ = ob.mse_loss(pred, tgt, dt, loss_scale=self.loss_scale, dpred_out=dpred[n_ref:], dpred_nchw_out=dpn[n_ref:])
         # conv_out backward: weight / bias gradients in place (padded to 8 rows), data gradient by the direct conv
-        ob.gemm_tn(dpred, hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=True, scale=gs)
-        ob.colsum(dpred, out=P.g("conv_out.bias").view(1, 8), accumulate=True, scale=gs)
+        ob.gemm_tn(dpred, hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=P.acc("conv_out.weight"), scale=gs)
+        ob.colsum(dpred, out=P.g("conv_out.bias").view(1, 8), accumulate=P.acc("conv_out.bias"), scale=gs)
         wdo = P.p("conv_out.weight")[:oc].view(oc, 9, c0).flip(1).permute(2, 1, 0).contiguous()     # [c0][tap'][oc] fp32
         dhn = ops.conv_small(dpn, wdo, None, c0, 9, dt)
         tape.accum(tproj, dtproj)        # seeds of the two conditioning paths: their buffers fill up during the walk
         tape.accum(kv_all, dkv_all)
         tape.backward(hn, dhn)
+        P.finish_step()
+        self._freeze_derived()
         return loss, pred
 
     # ------------------------------------------------------------------ optimizer (T:1186-1194, T:1217-1223, T:1393-1394)

@@ -463,6 +463,12 @@ int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream);
 int dfw_weight_relayout(const void* x, void* y, int32_t R, int32_t C, int64_t ldx, int64_t ldy, int32_t nb, int64_t x_bs,
                         int64_t y_bs, int32_t flip, dfw_stream_t stream);
 
+/* Every re-layout of a training step in one launch.  items: DEVICE array of n_items records of twelve int64_t
+ * { x, y, R, C, ldx, ldy, x_bs, y_bs, nb, flip, block_begin, 0 } -- the dfw_weight_relayout arguments of the item (x / y
+ * as addresses) and the index of its first block in the flattened grid: block_begin[0] = 0, block_begin[i+1] =
+ * block_begin[i] + ceil(C/64) * ceil(R/64) * nb; total_blocks = the sum.  Same alignment rules as above (caller-checked). */
+int dfw_weight_relayout_batch(const void* items, int32_t n_items, int64_t total_blocks, dfw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

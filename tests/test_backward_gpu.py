@@ -400,3 +400,24 @@ def test_weight_relayout(B, dtype):
     assert torch.equal(ob.conv3x3_wd(pack_conv3x3(cw).cuda(), 128).cpu(), pack_conv3x3_dgrad(cw))
     cw = rnd((8, 320, 3, 3), dtype, 3)
     assert torch.equal(ob.conv3x3_wd(pack_conv3x3(cw).cuda(), 8).cpu(), pack_conv3x3_dgrad(cw))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_relayout_batch_equals_single_launches(B, dtype):
+    """The one-launch table form (every derived copy of a training step) writes the same bits as the per-weight launches,
+    and re-running it after the sources changed refreshes the copies in place."""
+    ops, ob = B
+    ws = [rnd((320, 1280), dtype, 1).cuda(), rnd((64, 9 * 128), dtype, 2).cuda(), rnd((8, 72), dtype, 3).cuda(),
+          rnd((1280, 320), dtype, 4).cuda()]
+    kinds = ["T", "D", "T", "T"]
+    singles = [ob.linear_wt(w) if k == "T" else ob.conv3x3_wd(w, w.shape[0]) for k, w in zip(kinds, ws)]
+    ys = [torch.zeros_like(s) for s in singles]
+    table = ob.relayout_table(list(zip(kinds, ws, ys)), "cuda")
+    ob.weight_relayout_batch(table)
+    for y, s in zip(ys, singles):
+        assert torch.equal(y, s)
+    for w in ws:
+        w.mul_(-2)
+    ob.weight_relayout_batch(table)
+    for k, w, y in zip(kinds, ws, ys):
+        assert torch.equal(y, ob.linear_wt(w) if k == "T" else ob.conv3x3_wd(w, w.shape[0]))
