@@ -19,6 +19,15 @@
 #include "common.h"
 #include "attention_common.h"
 
+#ifndef DFW_FSA_BWD_PRIO
+#define DFW_FSA_BWD_PRIO 1
+#endif
+#if DFW_FSA_BWD_PRIO
+#define DFW_BWD_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define DFW_BWD_PRIO(x) ((void)0)
+#endif
+
 namespace dfw {
 
 struct FsaBwdP {
@@ -148,9 +157,12 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
     // S^T = K Q^T - lse ;  dP^T = V dO^T - delta   (row constants as initial accumulators)
     f32x16 s[2], dp[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[kb][r] = qok ? nlse : 0.f; dp[kb][r] = ndelta; }
+    DFW_BWD_PRIO(1);           // the MFMA chains outrank the other waves' softmax VALU (forward: +9 %)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
         const int row = kb * 32 + lr;
@@ -160,6 +172,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
         dp[kb] = Tr<T>::mfma(vf, dof[ss], dp[kb]);
       }
     }
+    DFW_BWD_PRIO(0);
     // dS^T = P^T o dP^T ; rows of S^T are keys: (r & 3) + 8 (r >> 2) + 4 lh within the 32-key block
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
         s[kb][r] = pr * dp[kb][r];
       }
     // dQ^T += K^T dS^T
+    DFW_BWD_PRIO(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -189,6 +203,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
           o[d] = Tr<T>::mfma(kf, pf, o[d]);
         }
       }
+    DFW_BWD_PRIO(0);
     if (more) write_lds(smem + (cur ^ 1) * 3 * TILE);
     __syncthreads();
     cur ^= 1;
@@ -296,6 +311,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
         s[r] = stats[0][qi];
         dp[r] = stats[1][qi];
       }
+      DFW_BWD_PRIO(1);
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
         const int row = qb * 32 + lr;
@@ -304,6 +320,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
         s = Tr<T>::mfma(qa, kf[ss], s);
         dp = Tr<T>::mfma(da, vf[ss], dp);
       }
+      DFW_BWD_PRIO(0);
       typename Tr<T>::v8 pf[2], sf[2];       // P and dS as B operands: k-step t2 <- registers 8 t2 .. 8 t2 + 7
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
         sf[r >> 3][r & 7] = (T)(pr * dp[r]);
       }
       // dV^T += dO^T P ; dK^T += Q^T dS   (A fragments: transposed reads, rows in the accumulator's k order)
+      DFW_BWD_PRIO(1);
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const int row0 = qb * 32 + 16 * t2 + 4 * lh + tq, row1 = row0 + 8;
@@ -327,6 +345,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
           dk[d] = Tr<T>::mfma(qa, sf[t2], dk[d]);
         }
       }
+      DFW_BWD_PRIO(0);
     }
     __syncthreads();                  // every wave is done reading this tile
     if (more) write_lds();
