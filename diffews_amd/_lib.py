@@ -33,7 +33,8 @@ class FsaArgs(C.Structure):
                 ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32), ("n_bank", _i32), ("nshot", _i32),
                 ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldkb", _i32), ("ldvb", _i32), ("ldo", _i32),
                 ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("kb_bs", _i64), ("vb_bs", _i64), ("o_bs", _i64),
-                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32), ("q_prescaled", _i32), ("lse", _vp)]
+                ("scale", _f32), ("dtype", _i32), ("n_plain", _i32), ("q_prescaled", _i32), ("lse", _vp),
+                ("workspace", _vp), ("workspace_bytes", _sz)]
 
 
 class XattnArgs(C.Structure):
@@ -95,7 +96,8 @@ class LayerNormBwdArgs(C.Structure):
 class FsaBwdArgs(C.Structure):
     _fields_ = [("qkv", _vp), ("out", _vp), ("dout", _vp), ("lse", _vp), ("delta", _vp), ("dqkv", _vp),
                 ("batch", _i32), ("heads", _i32), ("n", _i32), ("nshot", _i32), ("n_plain", _i32),
-                ("ld", _i32), ("ldo", _i32), ("ldd", _i32), ("scale", _f32), ("dtype", _i32)]
+                ("ld", _i32), ("ldo", _i32), ("ldd", _i32), ("scale", _f32), ("dtype", _i32),
+                ("workspace", _vp), ("workspace_bytes", _sz)]
 
 
 class XattnBwdArgs(C.Structure):
@@ -132,6 +134,7 @@ SYMBOLS = {
     "dfw_gemm_gn_chunks": (_i32, [C.POINTER(GemmArgs)]),
     "dfw_gemm_gn_input_ok": (_i32, [C.POINTER(GemmArgs)]),
     "dfw_fsa_attention": (_i32, [C.POINTER(FsaArgs), _vp]),
+    "dfw_fsa_workspace_bytes": (_sz, [C.POINTER(FsaArgs)]),
     "dfw_cross_attention": (_i32, [C.POINTER(XattnArgs), _vp]),
     "dfw_groupnorm": (_i32, [C.POINTER(GroupNormArgs), _vp]),
     "dfw_groupnorm_workspace_bytes": (_sz, [C.POINTER(GroupNormArgs)]),
@@ -159,6 +162,7 @@ SYMBOLS = {
     "dfw_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_fsa_attention_bwd": (_i32, [C.POINTER(FsaBwdArgs), _vp]),
+    "dfw_fsa_attention_bwd_workspace_bytes": (_sz, [C.POINTER(FsaBwdArgs)]),
     "dfw_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
     "dfw_cross_attention_bwd": (_i32, [C.POINTER(XattnBwdArgs), _vp]),
     "dfw_cross_attention_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

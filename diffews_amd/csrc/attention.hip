@@ -41,6 +41,12 @@ struct FsaP {
   float c;  // scale * log2(e)
   int pre;  // q already carries c (dfw_fsa_args.q_prescaled)
   float* lse;  // optional [batch][heads][n_q]: log2-sum-exp2 of the (scaled) scores, for the backward
+  // Key split of the bank-reading images (lock-step launches with many shots: a query row walks (1 + nshot) x as many keys
+  // as a support row, and its few workgroups would be the critical path): such an image appears nsplit times in the grid,
+  // each instance walks a contiguous range of the key segments [own ; shot 0 ; ...] and leaves its un-normalised
+  // accumulator, running maximum and sum in `part`; fsa_combine_kernel merges them.  nsplit = 1: nothing of this.
+  int nsplit;
+  float* part;   // [(batch - n_plain) * nsplit][heads][n_q][68]: o[64] (un-normalised), m (log2 units), l, 2 pad
 };
 
 template <typename T>
@@ -301,6 +307,12 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
       b = (int)gridDim.z - 1 - (int)blockIdx.z;
     }
   }
+  int split = 0;
+  if (p.nsplit > 1 && b >= p.n_plain) {       // grid.z lists every bank-reading image nsplit times (after the plain ones)
+    const int v = b - p.n_plain;
+    split = v % p.nsplit;
+    b = p.n_plain + v / p.nsplit;
+  }
   const int bank_b = b - p.n_plain;          // episode index into the bank (< 0: own keys only)
   const int q0 = qblk * (NW * 32 * QB) + wave * (32 * QB);
   const uint32_t lds0 = lds_addr(smem);
@@ -325,8 +337,12 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   const int lrow = lane >> 3, slot = lane & 7;
   const int tiles_own = (p.n_kv + KT - 1) / KT;
   const int tiles_bank = (p.nshot > 0 && bank_b >= 0) ? (p.n_bank + KT - 1) / KT : 0;
-  const int ntiles = tiles_own + (tiles_bank ? p.nshot * tiles_bank : 0);
-  int ld_seg = 0, ld_tt = 0;   // segment / tile-in-segment of the next tile to load
+  // this instance's key segments [seg0, seg1) of [own ; shot 0 ; ...]
+  const int nseg = 1 + (tiles_bank ? p.nshot : 0);
+  const bool parted = p.nsplit > 1 && bank_b >= 0;
+  const int seg0 = parted ? split * nseg / p.nsplit : 0, seg1 = parted ? (split + 1) * nseg / p.nsplit : nseg;
+  const int ntiles = (seg0 == 0 ? tiles_own : 0) + (seg1 - (seg0 == 0 ? 1 : seg0)) * tiles_bank;
+  int ld_seg = seg0, ld_tt = 0;   // segment / tile-in-segment of the next tile to load
   auto issue = [&](int st) {
     const uint32_t dst = lds0 + (uint32_t)st * STAGE;
     const int key0 = ld_tt * KT;
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   // every tile's QK^T MFMAs -- which also drains the hand-counted K/V DMA ring early.  One full wait
   // here (the first tiles are needed by the first iteration anyway) removes them from the loop.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-  int c_tt = 0, c_own = 1;  // compute-side tile-in-segment / own-segment flag
+  int c_tt = 0, c_own = seg0 == 0 ? 1 : 0;  // compute-side tile-in-segment / own-segment flag
   typename Tr<T>::v8 pf[QB][4];   // P^T fragments of the tile between its softmax and its P.V
   // PRE, one query block per wave: on a tile that does not move the reference maximum only the FIRST 32 keys are
   // exponentiated before the P.V MFMAs start; the second 32 keys' exp2 / row-sum run in the gaps of the first four
@@ -670,6 +686,25 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
   const float l_tot = half_swap_sum(l_run[g]);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + g * 32 + lr;
+  if (parted) {
+    if (qrow < p.n_q) {
+      float* pr = p.part + ((((size_t)bank_b * p.nsplit + split) * p.heads + head) * p.n_q + qrow) * 68;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = o[g][d][4 * gg + e];
+          *(f32x4*)(pr + d * 32 + 8 * gg + 4 * lh) = v;
+        }
+      if (lh == 0) {
+        pr[64] = PRE ? m_run[g] : m_run[g] * p.c;
+        pr[65] = l_tot;
+      }
+    }
+    continue;
+  }
   if (qrow < p.n_q) {
     if (p.lse && lh == 0)   // exp2(s' - lse) is the row's probability (s' = scaled score in log2 units)
       p.lse[((size_t)b * p.heads + head) * p.n_q + qrow] = (PRE ? m_run[g] : m_run[g] * p.c) + __builtin_amdgcn_logf(l_tot);
@@ -685,6 +720,42 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 ? 2 : 4) * NW / 8 > 0 ? (QB == 2 
       }
   }
   }
+}
+
+// Merge of the key-split partial results: out = sum_s 2^(m_s - M) o_s / sum_s 2^(m_s - M) l_s, lse = M + log2(that sum).
+// One thread per (row, 4 output columns); splits visited in order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_combine_kernel(const FsaP p) {
+  const int nq_img = p.batch - p.n_plain;
+  const long long rows = (long long)nq_img * p.heads * p.n_q;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = e >> 4;
+  const int c4 = (int)(e & 15);
+  if (row >= rows) return;
+  const int qrow = (int)(row % p.n_q);
+  const long long t = row / p.n_q;
+  const int head = (int)(t % p.heads), bq = (int)(t / p.heads);
+  const float* base = p.part + ((((size_t)bq * p.nsplit) * p.heads + head) * p.n_q + qrow) * 68;
+  const size_t sstride = (size_t)p.heads * p.n_q * 68;
+  float M = -INFINITY;
+  for (int s2 = 0; s2 < p.nsplit; ++s2) M = fmaxf(M, base[s2 * sstride + 64]);
+  float L = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s2 = 0; s2 < p.nsplit; ++s2) {
+    const float* ps = base + s2 * sstride;
+    const float w = __builtin_amdgcn_exp2f(ps[64] - M);
+    L += w * ps[65];
+    const f32x4 v = *(const f32x4*)(ps + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += w * v[i];
+  }
+  const float inv = 1.0f / L;
+  const int b = p.n_plain + bq;
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = acc[i] * inv;
+  *(i32x2*)(p.out + ((size_t)b * p.o_bs + (size_t)qrow * p.ldo + head * 64 + c4 * 4) * sizeof(T)) = pack4<T>(v);
+  if (p.lse && c4 == 0) p.lse[((size_t)b * p.heads + head) * p.n_q + qrow] = M + __builtin_amdgcn_logf(L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -754,6 +825,32 @@ static int64_t extent(int batch, int64_t bs, int n, int ld, int heads) {
   return (int64_t)(batch - 1) * bs + (int64_t)(n - 1) * ld + (int64_t)heads * 64;
 }
 
+// Key split of the bank-reading images (see FsaP::nsplit): the smallest split count whose longest workgroup is no longer
+// the launch's critical path.  Work in key tiles per workgroup column: plain images 1 segment, bank readers 1 + nshot.
+static int fsa_split_count(const dfw_fsa_args* a) {
+  static const char* off = getenv("DFW_FSA_NOSPLIT");
+  if (off || a->nshot < 2 || a->n_q > 65536) return 1;
+  const int nq_img = a->batch - a->n_plain, nseg = 1 + a->nshot;
+  if (nq_img <= 0) return 1;
+  if ((long long)a->n_kv + (long long)a->nshot * a->n_bank < 8192) return 1;    // short rows: nothing worth a second kernel
+  const int rows_per_wg = a->n_q <= 1024 ? 128 : 256;
+  const long long wg_per_img = (long long)a->heads * ((a->n_q + rows_per_wg - 1) / rows_per_wg);
+  const long long slots = a->n_q <= 1024 ? 1024 : 512;            // resident workgroups (4 x 256-thread / 2 x 512-thread per CU)
+  const double total = (double)wg_per_img * ((double)a->n_plain + (double)nq_img * nseg);   // in units of one segment's tiles
+  const double fair = total / slots > 1.0 ? total / slots : 1.0;
+  if ((double)nseg <= 1.5 * fair) return 1;
+  for (int ns = 2; ns <= nseg; ++ns)
+    if ((double)((nseg + ns - 1) / ns) <= 1.25 * fair) return ns;
+  return nseg;
+}
+
+extern "C" size_t dfw_fsa_workspace_bytes(const dfw_fsa_args* a) {
+  if (!a || a->batch <= 0 || a->heads <= 0 || a->n_q <= 0) return 0;
+  const int ns = fsa_split_count(a);
+  if (ns <= 1) return 0;
+  return (size_t)(a->batch - a->n_plain) * ns * a->heads * a->n_q * 68 * sizeof(float);
+}
+
 extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->out) return DFW_EINVAL;
   if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kv <= 0 || a->nshot < 0) return DFW_EINVAL;
@@ -790,10 +887,20 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
   p.c = a->scale * 1.4426950408889634f;
   p.pre = a->q_prescaled ? 1 : 0;
   p.lse = a->lse;
+  // key split: only with a caller-provided workspace of dfw_fsa_workspace_bytes(); without one the launch is unsplit
+  p.nsplit = 1; p.part = nullptr;
+  {
+    const int ns = fsa_split_count(a);
+    if (ns > 1 && a->workspace && a->workspace_bytes >= dfw_fsa_workspace_bytes(a) && (((uintptr_t)a->workspace) & 15) == 0) {
+      p.nsplit = ns;
+      p.part = (float*)a->workspace;
+    }
+  }
+  const int grid_z = a->n_plain + (a->batch - a->n_plain) * p.nsplit;
   hipStream_t st = (hipStream_t)stream;
   static const char* v1 = getenv("DFW_FSA_V1");
   const bool bf = a->dtype == DFW_BF16;
-  if (v1 && a->n_plain == 0 && !a->q_prescaled && !a->lse) {
+  if (v1 && a->n_plain == 0 && !a->q_prescaled && !a->lse && p.nsplit == 1) {
     dim3 grid((a->n_q + 127) / 128, a->heads, a->batch);
     if (bf) hipLaunchKernelGGL((fsa_kernel<__bf16>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fsa_kernel<_Float16>), grid, dim3(256), 0, st, p);
@@ -803,7 +910,7 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
     if (var) sscanf(var, "%dx%d", &nw, &qb);
     qb = 1;   // the two-query-block variant was an experiment (never faster); one block per wave everywhere
     if (a->n_q <= 1024 && !var) { nw = 4; qb = 1; }   // short rows: 128-query workgroups balance the grid better (measured)
-    dim3 grid((a->n_q + nw * 32 * qb - 1) / (nw * 32 * qb), a->heads, a->batch);
+    dim3 grid((a->n_q + nw * 32 * qb - 1) / (nw * 32 * qb), a->heads, grid_z);
     const bool pre = a->q_prescaled != 0;
     if (nw == 8) {
       if (bf) { if (pre) hipLaunchKernelGGL((fsa_ring_kernel<__bf16, 8, 1, true>), grid, dim3(512), 0, st, p);
@@ -818,6 +925,13 @@ extern "C" int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream) {
     }
   }
   DFW_CHECK_LAUNCH();
+  if (p.nsplit > 1) {
+    const long long threads = (long long)(a->batch - a->n_plain) * a->heads * a->n_q * 16;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (bf) hipLaunchKernelGGL((fsa_combine_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fsa_combine_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

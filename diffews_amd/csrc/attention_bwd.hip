@@ -44,6 +44,11 @@ struct FsaBwdP {
   int n_kv, ldkv, lddkv;
   long long kvbs, dkvbs;
   uint32_t kv_bytes, voff;
+  // dQ key split (the forward's FsaP::nsplit): a bank-reading image appears nsplit times in the dQ grid, each instance
+  // walks a contiguous range of the key segments and leaves its partial dQ (fp32, already scaled) in `part`
+  // [(batch - n_plain) * nsplit][n][heads * 64]; fsa_dq_combine_kernel sums them in order.  dQ is linear in the keys.
+  int nsplit;
+  float* part;
 };
 
 __device__ __forceinline__ uint32_t row_off(int row, int chunk) {   // K-style image: b128 row reads
@@ -84,7 +89,13 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];   // [buf][K rows | K tr | V rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const int head = blockIdx.y;
+  int b = (int)gridDim.z - 1 - (int)blockIdx.z, split = 0;      // longest rows (the bank readers, at the end) first
+  if (p.nsplit > 1 && b >= p.n_plain) {
+    const int v = b - p.n_plain;
+    split = v % p.nsplit;
+    b = p.n_plain + v / p.nsplit;
+  }
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int bank_b = b - p.n_plain;
   const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);
@@ -112,6 +123,12 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
   const int tiles_own = (p.n_kv + KT - 1) / KT;
   const int tiles_bank = (p.nshot > 0 && bank_b >= 0) ? tiles_own : 0;
   const int ntiles = tiles_own + (tiles_bank ? p.nshot * tiles_bank : 0);
+  // this instance's key segments [seg0, seg1) of [own ; shot 0 ; ...] as a range of the global tile numbering
+  const int nseg = 1 + (tiles_bank ? p.nshot : 0);
+  const bool parted = p.nsplit > 1 && bank_b >= 0;
+  const int seg0 = parted ? split * nseg / p.nsplit : 0, seg1 = parted ? (split + 1) * nseg / p.nsplit : nseg;
+  const int t_begin = seg0 == 0 ? 0 : tiles_own + (seg0 - 1) * tiles_bank;
+  const int t_end = parted ? tiles_own + (seg1 - 1) * tiles_bank : ntiles;
   i32x4 gk[2], gv[2];
   auto issue = [&](int t) {
     int img = b, tt = t;
@@ -141,12 +158,12 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 
-  issue(0);
+  issue(t_begin);
   write_lds(smem);
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
     if (more) issue(t + 1);
     const char* kbuf = smem + cur * 3 * TILE;
     const char* ktr = kbuf + TILE;
@@ -208,7 +225,18 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
     __syncthreads();
     cur ^= 1;
   }
-  if (qok) {
+  if (qok && parted) {
+    float* pr = p.part + (((size_t)bank_b * p.nsplit + split) * p.n + qrow) * ((size_t)p.heads * 64) + head * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * p.scale;
+        *(f32x4*)(pr + d * 32 + 8 * g + 4 * lh) = v;
+      }
+  } else if (qok) {
     char* ob = p.dq + ((size_t)b * p.dbs + (size_t)qrow * p.ldd + head * 64) * sizeof(T);
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -220,6 +248,28 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
         *(i32x2*)(ob + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(v);
       }
   }
+}
+
+// dq[b][row][c] = sum over the splits (in order) of the partial dQ; one thread per 4 columns
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_dq_combine_kernel(const FsaBwdP p) {
+  const int C = p.heads * 64, c4n = C / 4;
+  const long long total = (long long)(p.batch - p.n_plain) * p.n * c4n;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c4 = (int)(e % c4n);
+  const long long r = e / c4n;
+  const int row = (int)(r % p.n), bq = (int)(r / p.n);
+  const float* base = p.part + (((size_t)bq * p.nsplit) * p.n + row) * (size_t)C + c4 * 4;
+  const size_t sstride = (size_t)p.n * C;
+  f32x4 acc = *(const f32x4*)base;
+  for (int s2 = 1; s2 < p.nsplit; ++s2) {
+    const f32x4 v = *(const f32x4*)(base + s2 * sstride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += v[i];
+  }
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  *(i32x2*)(p.dq + ((size_t)(p.n_plain + bq) * p.dbs + (size_t)row * p.ldd + c4 * 4) * sizeof(T)) = pack4<T>(v);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -592,6 +642,28 @@ extern "C" int dfw_silu(const void* a, const void* dy, void* y, int64_t n, int32
   return 0;
 }
 
+// Same rule as the forward's fsa_split_count (attention.hip), for the dQ grid: 128-row workgroups, up to 3 per CU.
+static int fsa_bwd_split_count(const dfw_fsa_bwd_args* a) {
+  static const char* off = getenv("DFW_FSA_NOSPLIT");
+  if (off || a->nshot < 2) return 1;
+  const int nq_img = a->batch - a->n_plain, nseg = 1 + a->nshot;
+  if (nq_img <= 0 || (long long)a->n * nseg < 8192) return 1;
+  const long long wg_per_img = (long long)a->heads * ((a->n + 127) / 128);
+  const double total = (double)wg_per_img * ((double)a->n_plain + (double)nq_img * nseg);
+  const double fair = total / 768.0 > 1.0 ? total / 768.0 : 1.0;
+  if ((double)nseg <= 1.5 * fair) return 1;
+  for (int ns = 2; ns <= nseg; ++ns)
+    if ((double)((nseg + ns - 1) / ns) <= 1.25 * fair) return ns;
+  return nseg;
+}
+
+extern "C" size_t dfw_fsa_attention_bwd_workspace_bytes(const dfw_fsa_bwd_args* a) {
+  if (!a || a->batch <= 0 || a->heads <= 0 || a->n <= 0) return 0;
+  const int ns = fsa_bwd_split_count(a);
+  if (ns <= 1) return 0;
+  return (size_t)(a->batch - a->n_plain) * ns * a->n * a->heads * 64 * sizeof(float);
+}
+
 extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream) {
   if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->delta || !a->dqkv) return DFW_EINVAL;
   if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->nshot < 0 || a->n_plain < 0 || a->n_plain > a->batch) return DFW_EINVAL;
@@ -624,10 +696,26 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
   p.scale = a->scale;
   p.n_kv = a->n; p.ldkv = a->ld; p.lddkv = a->ldd; p.kvbs = p.bs; p.dkvbs = p.dbs;
   p.kv_bytes = p.qkv_bytes - (uint32_t)(C * es); p.voff = (uint32_t)(C * es);
+  p.nsplit = 1; p.part = nullptr;
+  {
+    const int ns = fsa_bwd_split_count(a);
+    if (ns > 1 && a->workspace && a->workspace_bytes >= dfw_fsa_attention_bwd_workspace_bytes(a) && (((uintptr_t)a->workspace) & 15) == 0) {
+      p.nsplit = ns;
+      p.part = (float*)a->workspace;
+    }
+  }
   dim3 grid((a->n + 127) / 128, a->heads, a->batch);
-  if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  dim3 gridq((a->n + 127) / 128, a->heads, a->n_plain + (a->batch - a->n_plain) * p.nsplit);
+  if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), gridq, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), gridq, dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
+  if (p.nsplit > 1) {
+    const long long threads = (long long)(a->batch - a->n_plain) * a->n * (C / 4);
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (bf) hipLaunchKernelGGL((fsa_dq_combine_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fsa_dq_combine_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+  }
   if (bf) hipLaunchKernelGGL((fsa_bwd_dkv_kernel<__bf16>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fsa_bwd_dkv_kernel<_Float16>), grid, dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
@@ -672,6 +760,7 @@ extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream
   p.scale = a->scale;
   p.n_kv = a->n_kv; p.ldkv = a->ldkv; p.lddkv = a->lddkv; p.kvbs = a->kv_bs; p.dkvbs = a->dkv_bs;
   p.kv_bytes = (uint32_t)(ke * es); p.voff = (uint32_t)(vc - kc);
+  p.nsplit = 1; p.part = nullptr;
   dim3 gq((a->n_q + 127) / 128, a->heads, a->batch), gk((a->n_kv + 127) / 128, a->heads, a->batch);
   if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), gq, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), gq, dim3(256), 0, st, p);

@@ -209,11 +209,13 @@ def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
 
 
 def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None, n_plain=0,
-                  q_prescaled=False, lse=None):
+                  q_prescaled=False, lse=None, key_split=True):
     """KV-fusion self-attention.  q/k/v: [B, N, heads*64] views (token stride = stride(1));
     k_bank/v_bank: [(B-n_plain)*nshot, Nb, heads*64] views written by the support pass.
     n_plain: the first n_plain batch entries ignore the bank (lock-step [support ; query] launch).
-    q_prescaled: q already carries scale * log2(e) (linear(..., colscale=(C, FSA_QSCALE)))."""
+    q_prescaled: q already carries scale * log2(e) (linear(..., colscale=(C, FSA_QSCALE))).
+    key_split: let the library split the bank readers' key range over several workgroups when that balances the launch
+    (many shots; needs a scratch buffer, allocated here)."""
     B, N, Cq = q.shape
     assert Cq == heads * 64 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
@@ -235,6 +237,10 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
     if lse is not None:   # training: per-row log2-sum-exp2 for the backward
         assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (B, heads, N)
         a.lse = lse.data_ptr()
+    nbytes = L.lib().dfw_fsa_workspace_bytes(C.byref(a)) if (nshot >= 2 and key_split) else 0   # key split of the bank readers (many shots)
+    if nbytes:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     if gemm_hook is not None:   # bench.py roofline leg: QK^T + PV flops of this launch
         keys = n_plain * k.shape[1] + (B - n_plain) * (k.shape[1] + (nshot * k_bank.shape[1] if nshot else 0))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -193,7 +193,7 @@ def mse_loss(pred, target, dtype, loss_scale=1.0, dpred_out=None, dpred_nchw_out
     return loss, dpred
 
 
-def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None):
+def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None, key_split=True):
     """qkv [B, N, 3C] (q pre-scaled), out / dout [B, N, C], lse [B, heads, N] -> dqkv [B, N, 3C]."""
     B, N, C3 = qkv.shape
     Cq = heads * 64
@@ -207,7 +207,12 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     a.ld, a.ldo, a.ldd = C3, Cq, C3
     a.scale = scale if scale is not None else 64 ** -0.5
     a.dtype = _dt(qkv)
-    L.check(L.lib().dfw_fsa_attention_bwd(C.byref(a), _stream()), "dfw_fsa_attention_bwd")
+    lib = L.lib()
+    nbytes = lib.dfw_fsa_attention_bwd_workspace_bytes(C.byref(a)) if (nshot >= 2 and key_split) else 0
+    if nbytes:      # dQ key split of the bank readers (many shots)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    L.check(lib.dfw_fsa_attention_bwd(C.byref(a), _stream()), "dfw_fsa_attention_bwd")
     return dqkv
 
 

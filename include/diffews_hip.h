@@ -131,9 +131,14 @@ typedef struct {
   /* Optional (training): lse[batch][heads][n_q] fp32 = log2 of the row's sum of exp2(scaled score), so that
    * exp2(scaled score - lse) is the attention probability -- what dfw_fsa_attention_bwd recomputes P from. */
   float* lse;
+  /* Optional scratch of dfw_fsa_workspace_bytes() (16-byte aligned): with it, a lock-step launch whose bank-reading images
+   * walk many more keys than the plain ones (nshot >= 2) splits those images' key range over several workgroups and merges
+   * the partial softmax results (same mathematics, fp32 partials, fixed order); without it the launch is unsplit. */
+  void* workspace; size_t workspace_bytes;
 } dfw_fsa_args;
 
 int dfw_fsa_attention(const dfw_fsa_args* a, dfw_stream_t stream);
+size_t dfw_fsa_workspace_bytes(const dfw_fsa_args* a);
 
 /*
  * Cross-attention over a short context (attn2 of BasicTransformerBlock; L = 2 prompt tokens at
@@ -400,9 +405,13 @@ typedef struct {
   int32_t ld, ldo, ldd;
   float scale;
   int32_t dtype;
+  /* Optional scratch of dfw_fsa_attention_bwd_workspace_bytes() (16-byte aligned): the dQ kernel then splits the key range
+   * of the bank-reading images over several workgroups (partial dQ in fp32, summed in order), as the forward does. */
+  void* workspace; size_t workspace_bytes;
 } dfw_fsa_bwd_args;
 
 int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream);
+size_t dfw_fsa_attention_bwd_workspace_bytes(const dfw_fsa_bwd_args* a);
 
 /* The same backward with queries and keys / values in their own tensors (attn2 of the training step, T:1368-1375, on
  * the MFMA path: forward = dfw_fsa_attention with n_kv = 77 prompt tokens and lse requested).  q [batch][n_q][heads*64]

@@ -213,7 +213,8 @@ def _attn_ref(qkv, heads, b, nshot):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("b,nshot,heads,N", [(2, 0, 1, 64), (1, 1, 2, 256), (2, 2, 1, 100), (1, 3, 2, 200), (2, 1, 5, 64)])
+@pytest.mark.parametrize("b,nshot,heads,N", [(2, 0, 1, 64), (1, 1, 2, 256), (2, 2, 1, 100), (1, 3, 2, 200), (2, 1, 5, 64),
+                                             (1, 7, 2, 1100)])      # the last one takes the key-split path (fwd and dQ)
 def test_fsa_attention_backward(B, dtype, b, nshot, heads, N):
     """Forward with the per-row log-sum-exp + the two flash backward kernels vs torch autograd: dq / dk / dv of the
     lock-step batch, the support images' dk / dv collecting BOTH their own pass and their episode's query pass."""

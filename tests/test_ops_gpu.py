@@ -381,6 +381,44 @@ def test_fsa_attention_lockstep_launch(ops, dtype, b, nshot, heads, N, pre):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,nshot,heads,N,n_plain_mode", [(1, 7, 2, 1024, True), (2, 5, 1, 2048, True), (2, 3, 2, 2100, False)])
+def test_fsa_attention_key_split(ops, dtype, b, nshot, heads, N, n_plain_mode):
+    """Many shots: the bank-reading images' key range is split over several workgroups and the partial softmax results
+    merged (dfw_fsa_args.workspace).  Same result as the unsplit launch up to the merge's fp32 arithmetic, == SDPA over the
+    materialised concat, and the row log-sum-exp the backward reads is the merged one."""
+    import ctypes
+    from diffews_amd import _lib
+    C = heads * 64
+    n_ref = b * nshot
+    qkv = rnd((n_ref + b, N, 3 * C), dtype, 21).cuda()
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    q, qr = _prescale(q, True)
+    q, qr = q.contiguous(), qr.cuda()
+    if n_plain_mode:
+        args = (q, k, v, heads, k[:n_ref], v[:n_ref])
+        kw = dict(nshot=nshot, n_plain=n_ref, q_prescaled=True)
+        Bt = n_ref + b
+    else:
+        args = (q[n_ref:], k[n_ref:], v[n_ref:], heads, k[:n_ref], v[:n_ref])
+        kw = dict(nshot=nshot, q_prescaled=True)
+        Bt = b
+    lse1 = torch.empty(Bt, heads, N, dtype=torch.float32, device="cuda")
+    lse0 = torch.empty_like(lse1)
+    split = ops.fsa_attention(*args, lse=lse1, **kw)
+    plain = ops.fsa_attention(*args, lse=lse0, key_split=False, **kw)
+    a = _lib.FsaArgs()
+    a.batch, a.heads, a.n_q, a.n_kv, a.n_bank, a.nshot, a.n_plain = Bt, heads, N, N, N, nshot, (n_ref if n_plain_mode else 0)
+    assert _lib.lib().dfw_fsa_workspace_bytes(ctypes.byref(a)) > 0, "this shape is expected to take the split path"
+    assert rel(split, plain) < TOL[dtype]      # two 16-bit roundings of P against different running maxima, one of the output
+    assert float((lse1 - lse0).abs().max()) < 1e-3
+    sh = lambda t: t.float().reshape(t.shape[0], -1, heads, 64).transpose(1, 2)
+    kq = torch.cat([k[n_ref:], k[:n_ref].reshape(b, nshot * N, C)], dim=1)
+    vq = torch.cat([v[n_ref:], v[:n_ref].reshape(b, nshot * N, C)], dim=1)
+    ref_q = F.scaled_dot_product_attention(sh(qr[n_ref:]), sh(kq), sh(vq)).transpose(1, 2).reshape(b, N, C)
+    assert rel(split[-b:], ref_q) < 1.5 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("L", [2, 77])
 def test_cross_attention(ops, dtype, L):
     B, heads, N = 2, 3, 300
