@@ -8,6 +8,15 @@
 #include "common.h"
 #include "attention_common.h"
 
+#ifndef DFW_TN_PRIO_ON
+#define DFW_TN_PRIO_ON 1
+#endif
+#if DFW_TN_PRIO_ON
+#define DFW_TN_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define DFW_TN_PRIO(x) ((void)0)
+#endif
+
 namespace dfw {
 
 // ---------------------------------------------------------------------------------------------
@@ -303,10 +312,12 @@ __global__ __launch_bounds__(256 * NSA * NSB) void gemm_tn_ring_kernel(const TnP
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fa[i][j] = alo[j]; fa[i][4 + j] = ahi[j]; fb[i][j] = blo[j]; fb[i][4 + j] = bhi[j]; }
       }
+      DFW_TN_PRIO(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = Tr<T>::mfma(fa[i], fb[j], acc[i][j]);
+      DFW_TN_PRIO(0);
     }
   }
   // D layout: col = lane & 31 (k), row = (r & 3) + 8 * (r >> 2) + 4 * lh (n)
