@@ -357,8 +357,9 @@ static int launch_tile(const GemmP& p, hipStream_t st) {
 //   split-K adds the fp32 slab round trip and a second launch.
 // The weight-bound 8x8 / 16x16 UNet levels pick 128-wide tiles with split-K 4..8, the token GEMMs of
 // the 64x64 level pick narrow tiles, the big VAE convs 128x128 without split.
-struct TileCost { int bm, bn; float R, L; };
-static const TileCost kTiles[3] = {{128, 128, 1.67f, 0.70f}, {128, 64, 2.8f, 0.50f}, {64, 64, 3.7f, 0.40f}};
+struct TileCost { int bm, bn; float R, L, E; };
+static const TileCost kTiles[3] = {{128, 128, 1.67f, 0.70f, 0.f}, {128, 64, 2.8f, 0.50f, 0.f}, {64, 64, 3.7f, 0.40f, 0.f}};
+static const TileCost kLinTiles[3] = {{128, 128, 5.29f, 0.312f, 1.94f}, {128, 64, 8.52f, 0.182f, 0.13f}, {64, 64, 12.9f, 0.145f, 0.f}};
 
 static void plan_gemm(GemmP& p, int& bm, int& bn) {
   static const char* force = getenv("DFW_GEMM_TILE");  // experiments only: "128x128", "128x64", "64x64"
@@ -378,12 +379,25 @@ static void plan_gemm(GemmP& p, int& bm, int& bn) {
       if (!fixed_sk && sk > 1 && (!can_split || p.nk / sk < 8)) continue;
       const int use_sk = fixed_sk ? p.splitk : sk;
       const double blocks = tiles * use_sk, ksteps = (double)p.nk / use_sk;
-      const double busy = blocks < 256.0 ? blocks : 256.0;
-      double t_us = blocks * ksteps / busy / tc.R;
-      const double crit = ksteps * tc.L * (blocks > 256.0 * 2 ? 1.0 : 1.0);
-      if (crit > t_us) t_us = crit;
-      t_us += 3.0;
-      if (use_sk > 1) t_us += 3.0 + 2.0 * use_sk * (double)p.M * p.N * 4.0 / 3.0e6;
+      double t_us;
+      if (p.taps == 1) {
+        // Linear layers (short K: 10..160 K-steps): occupancy-quantised form, re-fitted on the lock-step batch of 8 latents
+        // (scratch/sweep_plan.py, 3 tiles x 5 split factors x 15 shapes): the busiest CU runs ceil(blocks / 256) workgroups
+        // at min(throughput R, n / latency L) K-steps per us and pays a per-tile prologue / epilogue E.  The older form
+        // below mis-ranked the 128 x 128 tile on these shapes by up to 54 % (8192 x 640 x 640: 25.2 vs 17.1 us).
+        const TileCost& tl = kLinTiles[t];
+        const double ncu = (double)(long long)((blocks + 255.0) / 256.0);
+        const double rate = tl.R < ncu / tl.L ? tl.R : ncu / tl.L;
+        t_us = ncu * (ksteps / rate + tl.E) + 3.0;
+        if (use_sk > 1) t_us += 2.0 * use_sk * (double)p.M * p.N * 4.0 / 3.0e6;
+      } else {
+        const double busy = blocks < 256.0 ? blocks : 256.0;
+        t_us = blocks * ksteps / busy / tc.R;
+        const double crit = ksteps * tc.L;
+        if (crit > t_us) t_us = crit;
+        t_us += 3.0;
+        if (use_sk > 1) t_us += 3.0 + 2.0 * use_sk * (double)p.M * p.N * 4.0 / 3.0e6;
+      }
       if (t_us < best) { best = (float)t_us; best_t = t; best_sk = use_sk; }
       if (fixed_sk) break;
     }
