@@ -746,6 +746,18 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   const bool rag_ok = rag || ((p.N + 127) / 128 * 128 - p.N) * 10 <= p.N;
   if ((p.N % 128) == 0 || ((p.N % 64) == 0 && p.N > 128 && !p.geglu && rag_ok)) {
     const BigCfg* list = (p.N % 256) == 0 ? wide : narrow;
+    // Short-K linears whose 256 x 256 tile count quantises badly over the 256 CUs (2048 x 10240 x 1280 GEGLU: 320 tiles =
+    // 1.25 rounds; 49152 x 512 x 512: 1.5 rounds) run 12-14 % faster on 256 x 128 x 64 (scratch/sweep_big.py); long-K
+    // convs keep the wide tile whatever the round count (49152 x 512 x 4608: 230 vs 251 us).
+    if (list == wide && p.taps == 1 && p.K <= 1536 && big_cfg_ok(p, wide[0]) && big_cfg_ok(p, wide[1])) {
+      const long long z = p.batch > 1 ? p.batch : 1;
+      const long long t0 = (long long)((p.M + 255) / 256) * (p.N / 256) * z, t1 = (long long)((p.M + 255) / 256) * (p.N / 128) * z;
+      const double e0 = (double)t0 / (double)((t0 + 255) / 256 * 256), e1 = (double)t1 / (double)((t1 + 255) / 256 * 256);
+      if (e0 < 0.8 && e1 > e0 + 0.1) {
+        bm = wide[1].bm; bn = wide[1].bn; bk = wide[1].bk;
+        return true;
+      }
+    }
     for (int i = 0; i < 3; ++i)
       if (big_cfg_ok(p, list[i])) {
         bm = list[i].bm; bn = list[i].bn; bk = list[i].bk;
