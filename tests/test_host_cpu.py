@@ -321,3 +321,46 @@ def test_two_rank_bucketed_gradient_all_reduce_is_bit_exact(tmp_path):
     g = g0.clone()
     assert allreduce_flat_gradient(g) is g and torch.equal(g, g0)
     assert poly_lr(1e-4, 0, 10) == pytest.approx(1e-4) and poly_lr(1e-4, 10, 10) == pytest.approx(1e-7)
+
+
+def test_kernel_plans_of_the_baseline_shapes():
+    """Host-side planning (no GPU call): which kernel the library picks for the shapes of BASELINE configs[1] / [4], and the
+    key-split plan of the many-shot attention launches -- the choices DESIGN.md section 3 states."""
+    import ctypes as C
+    from diffews_amd import _lib
+    lib = _lib.lib()
+
+    def name(M, N, K, taps=1, H=0, W=0):
+        a = _lib.GemmArgs()
+        a.A = a.W = a.C = 4096                      # never dereferenced by the planner
+        a.M, a.N, a.K, a.lda, a.ldc = M, N, K, K // taps, N
+        a.a_elems, a.w_elems = M * (K // taps), N * K
+        a.taps, a.Cin = taps, K // taps
+        a.Hi = a.Ho = H
+        a.Wi = a.Wo = W
+        a.stride, a.pad = 1, 1 if taps == 9 else 0
+        a.rows_per_img = H * W if taps == 9 else 0
+        a.out_scale, a.batch, a.dtype = 1.0, 1, _lib.BF16
+        buf = C.create_string_buffer(64)
+        rc = lib.dfw_gemm_kernel_name(C.byref(a), buf, 64)
+        assert rc == 0, rc
+        return buf.value.decode()
+
+    # VAE encoder, 12 images at 512^2: the N = 128 layers on the LDS-resident-patch kernel, the wide ones on gemm_big
+    assert name(12 * 512 * 512, 128, 9 * 128, 9, 512, 512).startswith("conv_patch_kernel<bf16,512,128")
+    assert name(12 * 256 * 256, 256, 9 * 256, 9, 256, 256).startswith("gemm_big_kernel<bf16,256,256,32")
+    # UNet, lock-step batch of 8 latents: narrow tiles for the short-K linears, the ragged 960-column QKV on gemm_big
+    assert name(8192, 640, 640) in ("gemm_kernel<bf16,64,64,lin>", "gemm_kernel<bf16,128,64,lin>")   # never 128 x 128 (+47 %)
+    assert name(32768, 960, 320).startswith("gemm_big_kernel<bf16,512,128")
+    assert name(32768, 320, 320).startswith("gemm_kernel<bf16,")
+
+    def fsa_ws(batch, n_plain, nshot, heads, n):
+        a = _lib.FsaArgs()
+        a.batch, a.heads, a.n_q, a.n_kv, a.n_bank, a.nshot, a.n_plain = batch, heads, n, n, n, nshot, n_plain
+        return lib.dfw_fsa_workspace_bytes(C.byref(a))
+
+    assert fsa_ws(8, 4, 1, 5, 4096) == 0                        # configs[1] (1-shot): never split
+    per_split = 5 * 4096 * 68 * 4                                # one bank-reading image, all heads: bytes per split
+    assert fsa_ws(8, 7, 7, 5, 4096) == 4 * per_split            # configs[4] (7-shot): the query image's 8 segments -> 4 splits
+    assert fsa_ws(12, 10, 5, 5, 4096) == 2 * 2 * per_split      # configs[2] (5-shot, b = 2): two query images x 2 splits
+    assert fsa_ws(8, 7, 7, 20, 256) == 0                         # 16x16 level: rows too short to be worth a second kernel
