@@ -203,8 +203,23 @@ __global__ __launch_bounds__(256 * NSA * NSB) void gemm_tn_ring_kernel(const TnP
   const int lh = lane >> 5;
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   const int ntk = (p.Kc + NSB * 128 - 1) / (NSB * 128);
-  const int n0 = ((int)blockIdx.x / ntk) * (NSA * 128), k0 = ((int)blockIdx.x % ntk) * (NSB * 128);
-  const int split = blockIdx.y, z = blockIdx.z;
+  // XCD-aware walk: workgroups go round-robin over the 8 XCDs in launch order, and every tile (and tap) of one split
+  // reads the same rows of A and B -- so the launch-order index is re-read as (XCD c, its k-th workgroup) -> logical
+  // index c * (total / 8) + k with the tile fastest, then the tap / batch, then the split: each XCD's L2 serves whole
+  // splits instead of an eighth of every split.
+  int tile_x = blockIdx.x, split = blockIdx.y, z = blockIdx.z;
+  {
+    const long long gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    if ((total & 7) == 0 && total >= 64) {
+      const long long id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+      long long l = (id & 7) * (total >> 3) + (id >> 3);
+      tile_x = (int)(l % gx);
+      l /= gx;
+      z = (int)(l % gz);
+      split = (int)(l / gz);
+    }
+  }
+  const int n0 = (tile_x / ntk) * (NSA * 128), k0 = (tile_x % ntk) * (NSB * 128);
   const int tap = z % p.taps, bb = z / p.taps;
   const int b1 = bb / p.batch2, b2 = bb - b1 * p.batch2;
   const char* Ab = p.A + ((size_t)b1 * p.strideA + (size_t)b2 * p.strideA2) * sizeof(T);
