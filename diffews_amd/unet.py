@@ -209,7 +209,11 @@ class MyUNet2DConditionModel:
         cfg.update(kwargs)
         self.config = _Cfg(cfg)
         if torch_dtype not in (torch.bfloat16, torch.float16):
-            raise ValueError("engine storage dtype must be torch.bfloat16 or torch.float16")
+            raise ValueError(
+                "engine storage dtype must be torch.bfloat16 or torch.float16: the MI355X path keeps activations in 16 bits "
+                "(fp32 accumulation, statistics and boundary tensors).  The reference launcher's default is fp32 "
+                "(evaluation_util/main_oss.py:335-336): pass --half_precision / torch_dtype=torch.float16 -- z0 then sits "
+                "1.5e-3 (relative L2) from the fp32 path, see DESIGN.md section 4")
         self.dtype = torch_dtype
         self.device = torch.device(device)
         L.lib()  # fail loudly right here if the HIP library is not built
