@@ -1004,6 +1004,12 @@ static int tn_plan(const dfw_gemm_tn_args* a, TnPlan& pl) {
     const double tt = rounds * (spp * t_step + t_fixed) + slab;
     if (tt < best) { best = tt; best_s = sp; }
   }
+  static const char* sscale = getenv("DFW_TN_SPLIT_SCALE");     // experiments: scale the chosen split count
+  if (sscale) {
+    best_s = (int)(best_s * atof(sscale) + 0.5);
+    if (best_s < 1) best_s = 1;
+    if (best_s > smax) best_s = smax;
+  }
   int spp = (steps + best_s - 1) / best_s;
   if (!pl.ring) spp = (spp + 1) & ~1;                            // the register-staged kernel walks 64-row steps
   pl.mchunk = spp * 32;
