@@ -838,6 +838,8 @@ static int fsa_split_count(const dfw_fsa_args* a) {
   const long long slots = a->n_q <= 1024 ? 1024 : 512;            // resident workgroups (4 x 256-thread / 2 x 512-thread per CU)
   const double total = (double)wg_per_img * ((double)a->n_plain + (double)nq_img * nseg);   // in units of one segment's tiles
   const double fair = total / slots > 1.0 ? total / slots : 1.0;
+  static const char* force = getenv("DFW_FSA_SPLITS");           // experiments: force the split count of eligible launches
+  if (force) { const int f = atoi(force); return f < 1 ? 1 : (f > nseg ? nseg : f); }
   if ((double)nseg <= 1.5 * fair) return 1;
   for (int ns = 2; ns <= nseg; ++ns)
     if ((double)((nseg + ns - 1) / ns) <= 1.25 * fair) return ns;

@@ -651,6 +651,8 @@ static int fsa_bwd_split_count(const dfw_fsa_bwd_args* a) {
   const long long wg_per_img = (long long)a->heads * ((a->n + 127) / 128);
   const double total = (double)wg_per_img * ((double)a->n_plain + (double)nq_img * nseg);
   const double fair = total / 768.0 > 1.0 ? total / 768.0 : 1.0;
+  static const char* force = getenv("DFW_FSA_SPLITS");           // experiments: force the split count of eligible launches
+  if (force) { const int f = atoi(force); return f < 1 ? 1 : (f > nseg ? nseg : f); }
   if ((double)nseg <= 1.5 * fair) return 1;
   for (int ns = 2; ns <= nseg; ++ns)
     if ((double)((nseg + ns - 1) / ns) <= 1.25 * fair) return ns;
