@@ -79,8 +79,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const GemmP p) {
   };
 
   // ---- patch loader: wave-instruction j (0..20) covers patch pixels 16j .. 16j+15; wave w issues
-  // j = w, w+8, w+16 (< 21).  lane -> pixel 16j + (lane>>2), slot lane&3, source chunk = slot ^ ((lane>>4)&3)
-  const int kc = (lane & 3) ^ ((lane >> 4) & 3);
+  // j = w, w+8, w+16 (< 21).  lane -> pixel 16j + (lane>>2), slot lane&3, source chunk = slot ^ ((pixel>>1)&3)
+  const int kc = (lane & 3) ^ ((lane >> 3) & 3);
   uint32_t pp_off[3];
   int pl_tile = tile0, pl_c = 0;              // next (tile, chunk) whose patch will be issued
   long long pl_issued = 0;                    // patches issued so far (parity = LDS buffer)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const GemmP p) {
       const int q = tq[u], sl = tid & 3;
       const int iy = tf_ct.oy0 - 1 + tqy[u], ix = tf_ct.ox0 - 1 + tqx[u];
       if (q < PW * PW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-        const int ch = tf_c * 32 + ((sl ^ ((q >> 2) & 3)) << 3);
+        const int ch = tf_c * 32 + ((sl ^ ((q >> 1) & 3)) << 3);
         i32x4* const ptr = (i32x4*)(pb + q * 64 + sl * 16);
         const f32x4* const cf = (const f32x4*)(coefbase + ch * 8);
         float f[8];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const GemmP p) {
     q0[i] = (r >> 4) * PW + (r & 15);
   }
   uint32_t lds_rw[NB];
-  const int sw4 = (lr >> 2) & 3;
+  const int sw4 = (lr >> 1) & 3;
 #pragma unroll
   for (int j = 0; j < NB; ++j) lds_rw[j] = (uint32_t)(wn * 64 + j * 32 + lr) * 64u + (uint32_t)((lh ^ sw4) << 4);
 
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const int q = q0[i] + tapoff;
-      pa[i] = (uint32_t)q * 64u + (uint32_t)((lh ^ ((q >> 2) & 3)) << 4);
+      pa[i] = (uint32_t)q * 64u + (uint32_t)((lh ^ ((q >> 1) & 3)) << 4);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

@@ -12,7 +12,9 @@
 //
 // K walk: chunk-major, tap-minor (step s of a tile -> chunk s / 9, tap s % 9), W columns tap * Cin + chunk * 32.
 // LDS: W ring 4 x BN x 64 B | patch 0 | patch 1 | 32 KiB epilogue staging (4 KiB per wave).
-// Patch pixel rows are 64 B with the 16-byte chunk swizzle slot = chunk ^ ((pixel >> 2) & 3): any 16 consecutive patch
+// Patch pixel rows are 64 B with the 16-byte chunk swizzle slot = chunk ^ ((pixel >> 1) & 3): any 8 consecutive patch
+// pixels hit 8 distinct 16-byte slots of a 128-byte bank row (measured conflict-free for ds_read_b128, scratch/proto/lds_swz.hip;
+// the ((pixel >> 2) & 3) form used before cost a 2-way conflict on every fragment read).  [old text:] any 16 consecutive patch
 // pixels hit 16 distinct 16-byte slots of a 256-byte bank row, so the 16x16x32 A-fragment reads are conflict-free at every
 // tap offset.  The DMA writes LDS linearly; the swizzle sits on the source address.
 //
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   auto row_to_m = [&](const TileC& c, int r) -> int { return (c.img * p.Ho + c.oy0 + (r >> 4)) * p.Wo + c.ox0 + (r & 15); };
 
   // ---- loaders.  lane -> (pixel or W row) lane >> 2 of the instruction's 16, LDS slot lane & 3, source chunk slot ^ swizzle
-  const int kc = (lane & 3) ^ ((lane >> 4) & 3);
+  const int kc = (lane & 3) ^ ((lane >> 3) & 3);
   // patch source offsets are recomputed at every issue (once per chunk: ~10 VALU per instruction) rather than kept in
   // PPW registers through the K loop
   int pl_img = 0, pl_oy0 = 0, pl_ox0 = 0;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   // ---- fragments
   f32x4 acc6[MB6][NB6];
   typename Tr<T>::v8 fa6[MB6], fw6[NB6];
-  const uint32_t rw6 = (uint32_t)(wn * 64 + l15) * RB + (uint32_t)((l4 ^ ((l15 >> 2) & 3)) << 4);
+  const uint32_t rw6 = (uint32_t)(wn * 64 + l15) * RB + (uint32_t)((l4 ^ ((l15 >> 1) & 3)) << 4);
   const int q00 = (wm * (WTM / 16)) * PW + l15;          // patch pixel of this lane for pixel-row block 0, tap (0, 0)
   auto reads = [&](int slot, int pbuf, int tap) __attribute__((always_inline)) {
     const char* bw = smem + slot * WSTAGE + rw6;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < MB6; ++i) {
       const int q = qb + i * PW;
-      fa6[i] = as_v8<T>(*(const i32x4*)(pb + q * RB + ((l4 ^ ((q >> 2) & 3)) << 4)));
+      fa6[i] = as_v8<T>(*(const i32x4*)(pb + q * RB + ((l4 ^ ((q >> 1) & 3)) << 4)));
     }
   };
   auto mfmas = [&]() __attribute__((always_inline)) {
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   f32x8 cfa, cfb;                                     // (scale, shift) of channels 0..3 / 4..7 of the group
   i32x4 raw;
   bool tr_on = false;
-  const int tr_off = lane * 64 + (((wave & 3) ^ ((lane >> 2) & 3)) << 4) + (wave >> 2) * 4096;
+  const int tr_off = lane * 64 + (((wave & 3) ^ ((lane >> 1) & 3)) << 4) + (wave >> 2) * 4096;
   auto item_ptr = [&](int i) __attribute__((always_inline)) -> i32x4* {
     return (i32x4*)(pbase + ((pl - 1) & 1) * PATCH + tr_off + i * 8192);
   };

@@ -6,7 +6,9 @@
 //
 // Structure (one workgroup per CU, 2 waves per SIMD):
 //   * K-step = 32; LDS is a ring of S = 4 stages of [(256 + BN) rows][32 k] (64-byte rows,
-//     16-byte chunks XOR-swizzled by ((row>>2)&3): conflict-free ds_read_b128 fragments);
+//     16-byte chunks XOR-swizzled by ((row>>1)&3): conflict-free ds_read_b128 fragments -- measured: the
+//     ((row>>2)&3) swizzle of rounds 1-2 had a 2-way conflict on every fragment read, SQ_LDS_BANK_CONFLICT = 50 % of
+//     SQ_LDS_IDX_ACTIVE, scratch/proto/lds_swz.hip: 116 vs 221 B/clk/CU);
 //   * staging is LDS-DMA (buffer_load_dwordx4 ... lds), issued from inline asm so that hipcc does
 //     not drain it: three stages stay in flight ACROSS the barriers, retired by a counted
 //     s_waitcnt vmcnt(N) (N = DMA instructions of the two younger stages), one barrier per K-step;
@@ -109,10 +111,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   // ---- loader: wave-instruction i of a wave covers tile rows (i*8 + wave)*RPI .. +RPI (1 KiB of
   // LDS, written linearly: lane -> row + lane/CH, 16-byte slot lane%CH).  The bank swizzle lives
   // on the SOURCE side: slot j of a row holds global chunk j ^ swz(row), with
-  //   BK = 32 (64-B rows):  swz = (row>>2)&3      BK = 64 (128-B rows, full cache lines): swz = (row>>1)&7
+  //   BK = 32 (64-B rows):  swz = (row>>1)&3      BK = 64 (128-B rows, full cache lines): swz = (row>>1)&7
   // which depends only on the lane (and the wave's parity), not on i.
   const int lrow = lane / CH;
-  const int kc = BK == 32 ? ((lane & 3) ^ ((lrow >> 2) & 3))
+  const int kc = BK == 32 ? ((lane & 3) ^ ((lrow >> 1) & 3))
                           : ((lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7));
   uint32_t a_off[SA];
   int a_iy0[SA], a_ix0[SA];
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   };
   // ---- fragment read addresses within a stage (k-substep s: ^ (s<<5))
   uint32_t lds_ra[MB], lds_rw[NB];
-  const int sw4 = BK == 32 ? ((lr >> 2) & 3) : ((lr >> 1) & 7);
+  const int sw4 = BK == 32 ? ((lr >> 1) & 3) : ((lr >> 1) & 7);
 #pragma unroll
   for (int i = 0; i < MB; ++i) lds_ra[i] = (uint32_t)(wm * WTM + i * 32 + lr) * RB + (uint32_t)((lh ^ sw4) << 4);
 #pragma unroll
@@ -360,9 +362,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
     f32x4 acc6[MB6][NB6];
     typename Tr<T>::v8 fa6[MB6], fw6[NB6];
     const int l15 = lane & 15, l4 = lane >> 4;
-    // block i / j is 16 rows = 1 KiB further on and the swizzle ((row >> 2) & 3) only sees row & 15:
+    // block i / j is 16 rows = 1 KiB further on and the swizzle ((row >> 1) & 3) only sees row & 15:
     // one base address per operand, the blocks are immediates of the ds_read
-    const uint32_t sw6 = (uint32_t)((l4 ^ ((l15 >> 2) & 3)) << 4);
+    const uint32_t sw6 = (uint32_t)((l4 ^ ((l15 >> 1) & 3)) << 4);
     const uint32_t ra6 = (uint32_t)(wm * WTM + l15) * RB + sw6;
     const uint32_t rw6 = (uint32_t)(BM + wn * 64 + l15) * RB + sw6;
     auto reads = [&](int slot) __attribute__((always_inline)) {
