@@ -454,9 +454,11 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % 16) != 0 || (p.Cin % 64) != 0) return false;
   if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0) return false;
   if (p.rows_per_img != p.Ho * p.Wo || (p.gn_coef && p.Cin > 1024)) return false;
-  // Default: the 512 x 128 tile for the N = 128 layers only (measured on MI355X: +8..11 % over gemm_big there, -3 % on
-  // the 256 x 256 tile, where the A stream is already amortised over 256 columns).  DFW_CONV_PATCH=1 enables both, 0 none.
-  // A conv that normalises its input (gn_coef) takes either tile: the deleted GroupNorm pass outweighs the 3 %.
+  // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  DFW_CONV_PATCH=1 also routes the
+  // N % 256 == 0 layers to the 256 x 256 tile: 3 % behind gemm_big with the conflicting LDS swizzle of the first version,
+  // 1.5..2 % ahead per kernel with the conflict-free one (1008 / 1222 / 1034 vs 988 / 1198 / 1007 TFLOP/s, same box) and
+  // neutral on the whole step (41.96 / 41.90 vs 41.96 / 41.85 ms), so the measured configuration stays the default.
+  // A conv that normalises its input (gn_coef) takes either tile.  0 disables the kernel.
   const bool only128 = (!on || on[0] != '1') && !p.gn_coef;
   if ((p.N % 256) == 0 && !only128) { bm = 256; bn = 256; }
   else if ((p.N % 128) == 0 && (p.N % 256) != 0) { bm = 512; bn = 128; }
