@@ -193,7 +193,7 @@ def train_main(args):
     from diffews_amd.train import UNetTrainer, allreduce_flat_gradient, poly_lr
     from diffews_amd.vae import AutoencoderKL
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    s = args.nshot if args.nshot != 1 else 7          # configs[4] is 7-shot unless --nshot says otherwise
+    s = 7 if args.nshot is None else args.nshot       # configs[4] is 7-shot; an explicit --nshot is always honoured
     res = args.res
     ucfg, vcfg = config.get("tiny_unet" if args.tiny else "sd21_unet"), config.get("tiny_vae" if args.tiny else "sd_vae")
     t0 = time.time()
@@ -290,7 +290,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="episodes per GPU per step")
-    ap.add_argument("--nshot", type=int, default=1)
+    ap.add_argument("--nshot", type=int, default=None,
+                    help="shots per episode; default 1 for the inference metric (configs[1]), 7 for --train (configs[4])")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--tiny", action="store_true", help="tiny-width model (debug only; not a valid bench line)")
@@ -339,7 +340,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, blobs = build_pipeline(dtype, tiny=args.tiny)
 
-    b, s, res = args.batch, args.nshot, args.res
+    b, s, res = args.batch, (1 if args.nshot is None else args.nshot), args.res
     bt = episodes.make_episode_batch(b, s, res, seed=100 + rank, device="cuda")
     cls = episodes.episode_class_ids(list(range(rank * b, rank * b + b))).cuda()
     meter = AverageMeter("coco", fold_class_ids("coco", 0), device="cuda")

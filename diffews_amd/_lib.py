@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
                 ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),
                 ("batch", _i32), ("strideA", _i64), ("strideW", _i64), ("strideC", _i64), ("dtype", _i32),
                 ("gn_partial", _vp), ("gn_groups", _i32), ("gn_in_coef", _vp), ("gn_in_silu", _i32),
-                ("colscale", _f32), ("colscale_n", _i32)]
+                ("colscale", _f32), ("colscale_n", _i32), ("residual_f32", _i32)]
 
 
 class FsaArgs(C.Structure):
@@ -48,12 +48,14 @@ class XattnArgs(C.Structure):
 class GroupNormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("stats_ws", _vp), ("stats_ws_bytes", _sz),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("ldx", _i32), ("ldy", _i32),
-                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pre_partial", _vp), ("pre_chunks", _i32), ("coef_out", _vp)]
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pre_partial", _vp), ("pre_chunks", _i32), ("coef_out", _vp),
+                ("x_f32", _i32)]
 
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp),
-                ("rows", _i32), ("C", _i32), ("ldx", _i32), ("ldy", _i32), ("eps", _f32), ("dtype", _i32)]
+                ("rows", _i32), ("C", _i32), ("ldx", _i32), ("ldy", _i32), ("eps", _f32), ("dtype", _i32),
+                ("x_f32", _i32)]
 
 
 class ConvSmallArgs(C.Structure):
@@ -121,13 +123,14 @@ class AttnBwdArgs(C.Structure):
 class AdamWArgs(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_sumsq", _vp), ("n", _i64),
                 ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_grad_norm", _f32),
-                ("step", _i32), ("shadow", _vp), ("shadow_dtype", _i32)]
+                ("step", _i32), ("shadow", _vp), ("shadow_dtype", _i32), ("found_inf", _vp)]
 
 
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dfw_version": (_i32, []),
     "dfw_error_string": (C.c_char_p, [_i32]),
+    "dfw_graph_memset_nodes": (_i32, [_vp, C.POINTER(_i32)]),
     "dfw_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dfw_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
     "dfw_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _sz]),
@@ -145,6 +148,7 @@ SYMBOLS = {
     "dfw_softmax_groups": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dfw_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dfw_concat_channels": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dfw_convert_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "dfw_timestep_embedding": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_seg_postprocess": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "dfw_seg_postprocess_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
@@ -161,6 +165,8 @@ SYMBOLS = {
     "dfw_elementwise": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dfw_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dfw_loss_grad": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dfw_convert_to_f32": (_i32, [_vp, _vp, _i64, _f32, _i32, _vp]),
     "dfw_fsa_attention_bwd": (_i32, [C.POINTER(FsaBwdArgs), _vp]),
     "dfw_fsa_attention_bwd_workspace_bytes": (_sz, [C.POINTER(FsaBwdArgs)]),
     "dfw_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),

@@ -860,6 +860,33 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// External loss gradient (torch autograd hands d loss / d pred to the UNet's backward): dpred = (T)(g * scale) as NHWC
+// [B][HW][8] and the same rounded values as NCHW fp32 -- what mse_kernel emits for the built-in loss.
+template <typename T>
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* g, T* dpred, float* dnchw, int B, int C, int HW, float scale) {
+  const long long total = (long long)B * C * HW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bc = e / HW;
+    const int p = (int)(e - bc * HW);
+    const long long b = bc / C;
+    const int c = (int)(bc - b * C);
+    const T r = (T)(g[e] * scale);
+    dpred[((size_t)b * HW + p) * 8 + c] = r;
+    if (dnchw) dnchw[e] = (float)r;
+  }
+}
+
+// storage dtype -> fp32 with a scale (the bf16 gradient all-reduce: sum in bf16 on the wire, back to fp32 * 1/world)
+template <typename T>
+__global__ __launch_bounds__(256) void to_f32_kernel(const char* x, float* y, long long n8, float scale) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n8; e += (long long)gridDim.x * 256) {
+    float f[8];
+    unpack8<T>(*(const i32x4*)(x + e * 8 * sizeof(T)), f);
+    *(f32x4*)(y + e * 8) = f32x4{f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale};
+    *(f32x4*)(y + e * 8 + 4) = f32x4{f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale};
+  }
+}
+
 __global__ __launch_bounds__(64) void fold_scalar_kernel(const float* part, float* out, int n, float scale) {
   float a = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) a += part[i];   // lane-strided, then a fixed butterfly
@@ -890,12 +917,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* part,
 // clip_grad_norm_ factor (T:1393) read from device memory: g *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)).
 struct AdamP {
   float* p; const float* g; float* m; float* v; const float* sumsq; void* shadow; int shadow_bf16;
+  int* found_inf;
   long long n;
   float lr, beta1, beta2, eps, wd, bc1, bc2, max_norm;
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamP a) {
   float clip = 1.f;
+  if (a.sumsq) {
+    // overflow guard (GradScaler's skipped step under accelerate mixed_precision='fp16', T:1017 / T:1239): one inf / NaN
+    // gradient makes the norm non-finite -- the whole update is then SKIPPED (master, both moments and the 16-bit shadow
+    // stay untouched) and the flag is raised for the host's dynamic loss scale
+    const float ssq = *a.sumsq;
+    const bool bad = !(ssq == ssq) || ssq > 3.0e38f;
+    if (a.found_inf && blockIdx.x == 0 && threadIdx.x == 0) *a.found_inf = bad ? 1 : 0;   // written every step: no memset needed
+    if (bad) return;
+  }
   if (a.sumsq && a.max_norm > 0.f) {
     const float c = a.max_norm / (sqrtf(*a.sumsq) + 1e-6f);
     clip = c < 1.f ? c : 1.f;
@@ -1287,6 +1324,29 @@ extern "C" int dfw_mse_loss(const float* pred, const float* target, void* dpred,
   return 0;
 }
 
+extern "C" int dfw_loss_grad(const float* g, void* dpred, float* dpred_nchw, int32_t B, int32_t C, int32_t HW, float scale,
+                             int32_t dtype, dfw_stream_t stream) {
+  if (!g || !dpred || B <= 0 || C <= 0 || C > 8 || HW <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = grid_for((long long)B * C * HW);
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((loss_grad_kernel<__bf16>), dim3(nb), dim3(256), 0, st, g, (__bf16*)dpred, dpred_nchw, B, C, HW, scale);
+  else hipLaunchKernelGGL((loss_grad_kernel<_Float16>), dim3(nb), dim3(256), 0, st, g, (_Float16*)dpred, dpred_nchw, B, C, HW, scale);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_convert_to_f32(const void* x, float* y, int64_t n, float scale, int32_t dtype, dfw_stream_t stream) {
+  if (!x || !y || n <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  if (n % 8 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return DFW_ESHAPE;
+  const int nb = grid_for(n / 8, 8192);
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((to_f32_kernel<__bf16>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const char*)x, y, (long long)(n / 8), scale);
+  else hipLaunchKernelGGL((to_f32_kernel<_Float16>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const char*)x, y, (long long)(n / 8), scale);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dfw_sumsq(const float* x, float* out, float* workspace, int64_t n, dfw_stream_t stream) {
   if (!x || !out || !workspace || n <= 0) return DFW_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1308,6 +1368,7 @@ extern "C" int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream) {
   p.bc1 = 1.0f - powf(a->beta1, (float)a->step);
   p.bc2 = 1.0f - powf(a->beta2, (float)a->step);
   p.max_norm = a->max_grad_norm;
+  p.found_inf = a->found_inf;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n, 8192)), dim3(256), 0, (hipStream_t)stream, p);
   DFW_CHECK_LAUNCH();
   return 0;

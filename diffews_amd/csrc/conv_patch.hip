@@ -452,7 +452,7 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
   if (on && on[0] == '0') return false;
   if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.ups || p.splitk > 1 || p.batch > 1) return false;
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % 16) != 0 || (p.Cin % 64) != 0) return false;
-  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0) return false;
+  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || p.res_f32) return false;
   if (p.rows_per_img != p.Ho * p.Wo || (p.gn_coef && p.Cin > 1024)) return false;
   // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  DFW_CONV_PATCH=1 also routes the
   // N % 256 == 0 layers to the 256 x 256 tile: 3 % behind gemm_big with the conflicting LDS swizzle of the first version,

@@ -19,7 +19,9 @@
 
 namespace dfw {
 
-template <typename T, int BM, int BN, bool CONV>
+// RF32: the residual is fp32 (dfw_gemm_args.residual_f32, the fp32 residual stream) -- its own instantiation so that
+// the 16-bit default path's epilogue compiles exactly as before.
+template <typename T, int BM, int BN, bool CONV, bool RF32 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int WTM = BM / 2, WTN = BN / 2, MB = WTM / 32, NB = WTN / 32;
   constexpr int SA = BM / 32, SW = BN / 32;
@@ -196,6 +198,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       int oy_, ox_, img_;
       const int m = row_to_m(c, wm * WTM + i * 32 + lr, oy_, ox_, img_);
       if (m >= p.M) continue;
+      if constexpr (RF32) {   // host guarantees: no split-K, N % 4 == 0, no GEGLU
+        const int img = p.rowbias ? (CONV && p.tw ? img_ : m / p.rows_per_img) : 0;
+        epi_block_rf32<T, NB>(p, Cb, m, img, c.n0 + wn * WTN + 4 * lh, acc[i]);
+        continue;
+      }
       if (p.geglu) {
         if constexpr (NB >= 2) {
 #pragma unroll
@@ -306,7 +313,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += t[i];
     }
-    epilogue4<T>(p, p.C, m, n, v);
+    if (p.res_f32) epilogue4<T, true>(p, p.C, m, n, v);
+    else epilogue4<T>(p, p.C, m, n, v);
   }
 }
 
@@ -334,10 +342,13 @@ static int launch_tile(const GemmP& p, hipStream_t st) {
   if (nwg > cap) nwg = cap;
   nwg = (nwg + 7) & ~7;
   dim3 grid(nwg, zdim);
+  const bool rf32 = p.res_f32 && p.splitk <= 1 && (p.N & 3) == 0 && !p.geglu;   // (split-K: the reduce pass adds the residual)
   if (p.taps == 1) {
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false>), grid, dim3(256), lds, st, q);
+    if (rf32) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true>), grid, dim3(256), lds, st, q);
+    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false>), grid, dim3(256), lds, st, q);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true>), grid, dim3(256), lds, st, q);
+    if (rf32) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true>), grid, dim3(256), lds, st, q);
+    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true>), grid, dim3(256), lds, st, q);
   }
   DFW_CHECK_LAUNCH();
   if (p.splitk > 1) {
@@ -431,6 +442,9 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   if (a->lda % 8 != 0) return DFW_ESHAPE;
   if (a->out_mode == DFW_OUT_T && (a->N % 4 == 0) && (a->ldc % 4 != 0)) return DFW_ESHAPE;
   if (a->residual && (a->N % 4 == 0) && (a->ldr % 4 != 0)) return DFW_ESHAPE;
+  if (a->residual_f32 && (!a->residual || a->N % 4 != 0 || a->ldr % 4 != 0 || ((uintptr_t)a->residual & 15) || a->act != DFW_ACT_NONE ||
+                          a->colscale_n > 0 || a->out_mode == DFW_OUT_NCHW_F32))
+    return DFW_ESHAPE;
   if (a->rowbias && a->ld_rowbias > 0 && (a->ld_rowbias % 4 != 0 || a->ld_rowbias < a->N)) return DFW_ESHAPE;
   if (a->a_elems <= 0 || a->w_elems <= 0) return DFW_EINVAL;
   if (a->a_elems * esz >= (1ll << 31) || a->w_elems * esz >= (1ll << 31)) return DFW_ERANGE;
@@ -465,6 +479,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.cs = a->colscale; p.cs_n = a->colscale_n;
   p.out_scale = a->out_scale; p.act = a->act; p.geglu = a->geglu; p.out_mode = a->out_mode;
   p.splitk = splitk; p.batch = batch;
+  p.res_f32 = a->residual_f32 ? 1 : 0;
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
   p.dtype_bf16 = a->dtype == DFW_BF16;
@@ -483,17 +498,13 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   int rc = fill_params(a, p, esz);
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
-  int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
+  int big_bm = 0, big_bn = 0, big_bk = 0;
   {
     int pbm = 0, pbn = 0;
     if (conv_patch_eligible(p, pbm, pbn)) {
       snprintf(buf, n, "conv_patch_kernel<%s,%d,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbm, pbn, p.gn_coef ? ",gn_in" : "");
       return 0;
     }
-  }
-  if (conv_halo_eligible(p, halo_bn)) {
-    snprintf(buf, n, "conv_halo_kernel<%s,256,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", halo_bn, p.gn_coef ? ",gn_in" : "");
-    return 0;
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
     snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d%s,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,
@@ -509,9 +520,8 @@ extern "C" int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a) {
   GemmP p;
   int esz;
   if (fill_params(a, p, esz)) return 0;
-  int halo_bn = 0, pbm = 0, pbn = 0;
+  int pbm = 0, pbn = 0;
   if (conv_patch_eligible(p, pbm, pbn)) return conv_patch_gn_chunks(p);
-  if (conv_halo_eligible(p, halo_bn)) return conv_halo_gn_chunks(p);
   return gemm_big_gn_chunks(p);
 }
 
@@ -520,8 +530,7 @@ extern "C" int32_t dfw_gemm_gn_input_ok(const dfw_gemm_args* a) {
   int esz;
   if (fill_params(a, p, esz)) return 0;
   int pbm = 0, pbn = 0;
-  if (p.gn_coef && conv_patch_eligible(p, pbm, pbn)) return 1;
-  return conv_halo_gn_input_ok(p) ? 1 : 0;
+  return (p.gn_coef && conv_patch_eligible(p, pbm, pbn)) ? 1 : 0;
 }
 
 extern "C" size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a) {
@@ -540,12 +549,11 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
     if (!a->workspace || a->workspace_bytes < (size_t)p.splitk * p.M * p.N * sizeof(float)) return DFW_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  int big_bm = 0, big_bn = 0, big_bk = 0, halo_bn = 0;
+  int big_bm = 0, big_bn = 0, big_bk = 0;
   {
     int pbm = 0, pbn = 0;
     if (conv_patch_eligible(p, pbm, pbn)) return launch_conv_patch(p, st);
   }
-  if (conv_halo_eligible(p, halo_bn)) return launch_conv_halo(p, st);
   if (p.gn_coef) return DFW_ESHAPE;   // no other kernel normalises its input
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);

@@ -728,7 +728,7 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   static const char* force = getenv("DFW_BIG_CFG");   // experiments: "256x128x64"
   if (off) return false;
   if (p.splitk > 1 || (p.N % 8) != 0) return false;
-  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE) return false;
+  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.res_f32) return false;
   if (force) {
     BigCfg c;
     c.occ = 1;

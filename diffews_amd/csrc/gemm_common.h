@@ -14,17 +14,18 @@ struct GemmP {
   float out_scale;
   float cs; int cs_n;   // output columns n < cs_n are scaled by cs instead of out_scale (0: none)
   int act, geglu, out_mode, splitk, batch;
+  int res_f32;          // residual is fp32 [M][ldr floats] (fp32 residual stream)
   long long strideA, strideW, strideC;
   int nk, cpt, ntn, ntm;
   int plan_bm, plan_bn, dtype_bf16;
   float* gn_partial; int gn_groups, gn_chunks;   // fused GroupNorm partial sums of the output (optional)
-  const float* gn_coef; int gn_silu;             // fused GroupNorm(+SiLU) of the input (conv_halo only)
+  const float* gn_coef; int gn_silu;             // fused GroupNorm(+SiLU) of the input (conv_patch GNIN only)
   int conv_chunk_major;                          // gemm_big conv: K walk = (channel chunk, tap) instead of (tap, chunk)
   int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
 };
 
 // Epilogue for 4 consecutive output channels n..n+3 of output row m (raw fp32 accumulators in v).
-template <typename T>
+template <typename T, bool RF32 = false>   // RF32: fp32 residual (only the split-K reduce pass instantiates it)
 __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n, float* v) {
   const bool vec = (p.N & 3) == 0;
   if (vec) {
@@ -40,7 +41,13 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
     }
     if (p.residual) {
       float r[4];
-      unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
+      if constexpr (RF32) {
+        const f32x4 t = *(const f32x4*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(float));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = t[i];
+      } else {
+        unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += r[i];
     }
@@ -50,7 +57,8 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, char* Cb, int m, int n
       if (n + i < p.N) {
         if (p.bias) v[i] += p.bias[n + i];
         if (p.rowbias) v[i] += p.rowbias[(size_t)(m / p.rows_per_img) * p.ldrb + n + i];
-        if (p.residual) v[i] += to_f(((const T*)p.residual)[(size_t)m * p.ldr + n + i]);
+        if (p.residual) v[i] += RF32 ? ((const float*)p.residual)[(size_t)m * p.ldr + n + i]
+                                     : to_f(((const T*)p.residual)[(size_t)m * p.ldr + n + i]);
       }
   }
 #pragma unroll
@@ -134,6 +142,52 @@ __device__ __forceinline__ void epi_block(const GemmP& p, char* Cb, int m, int i
     }
 }
 
+// The same block with an fp32 residual [M][ldr floats] (dfw_gemm_args.residual_f32: the fp32 residual stream): the
+// residual is summed in fp32 next to bias / row bias; output per out_mode (fp32 for the stream, storage dtype where the
+// result only feeds the next GEMM).  Kept apart from epi_block so that the 16-bit default path compiles unchanged.
+template <typename T, int NB>
+__device__ __forceinline__ void epi_block_rf32(const GemmP& p, char* Cb, int m, int img, int ncol0,
+                                               const f32x16 (&a)[NB]) {
+  f32x4 add[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ncol0 + 32 * j + 8 * g;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) {
+        b = *(const f32x4*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(float));
+        if (p.bias) {
+          const f32x4 r = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] += r[e];
+        }
+        if (p.rowbias) {
+          const f32x4 r = *(const f32x4*)(p.rowbias + (size_t)img * p.ldrb + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] += r[e];
+        }
+      }
+      add[j][g] = b;
+    }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ncol0 + 32 * j + 8 * g;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (a[j][4 * g + e] + add[j][g][e]) * p.out_scale;
+      if (p.out_mode == DFW_OUT_F32) {
+        const f32x4 o = {v[0], v[1], v[2], v[3]};
+        *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = o;
+      } else {
+        *(i32x2*)(Cb + ((size_t)m * p.ldc + n) * sizeof(T)) = pack4<T>(v);
+      }
+    }
+}
+
 // Tile coordinates of one output tile (uniform per workgroup).
 struct TileC {
   int m0, n0;                 // first output row (linear tiles) / first output channel
@@ -143,10 +197,6 @@ struct TileC {
 int launch_gemm_big(const GemmP& p, hipStream_t st);  // gemm_big.hip
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk);
 int gemm_big_gn_chunks(const GemmP& p);   // > 0: the planned big kernel can emit GroupNorm partials
-int launch_conv_halo(const GemmP& p, hipStream_t st);  // conv_halo.hip
-int conv_halo_gn_chunks(const GemmP& p);
-bool conv_halo_gn_input_ok(const GemmP& p);
-bool conv_halo_eligible(const GemmP& p, int& bn);
 int launch_conv_patch(const GemmP& p, hipStream_t st);  // conv_patch.hip
 bool conv_patch_eligible(const GemmP& p, int& bm, int& bn);
 int conv_patch_gn_chunks(const GemmP& p);

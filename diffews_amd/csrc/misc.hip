@@ -1,6 +1,7 @@
 // Small HBM-bound kernels around the MFMA path: boundary convs with tiny channel counts, row
 // softmax, transpose, channel concat, timestep embedding, segmentation post-processing + metric.
 #include "common.h"
+#include <stdlib.h>
 
 namespace dfw {
 
@@ -60,6 +61,10 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const CsP p) {
   for (int o = 0; o < 8; ++o) acc[o] = (acc[o] + bs[o]) * p.out_scale;
   if (p.out_mode == DFW_OUT_T) {
     *(i32x4*)(p.y + ((size_t)pix * p.ldy + co0) * sizeof(T)) = pack8<T>(acc);
+  } else if (p.out_mode == DFW_OUT_F32) {   // NHWC fp32 (the fp32 residual stream)
+    float* o = (float*)p.y + (size_t)pix * p.ldy + co0;
+    *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
   } else {
 #pragma unroll
     for (int o = 0; o < 8; ++o)
@@ -131,6 +136,16 @@ __global__ __launch_bounds__(256) void conv_small4_kernel(const CsP p) {
 #pragma unroll
       for (int o = 0; o < 8; ++o) v[o] = (acc[px][o] + bs[o]) * p.out_scale;
       *(i32x4*)(p.y + (((size_t)b * HW + pix + px) * p.ldy + co0) * sizeof(T)) = pack8<T>(v);
+    }
+  } else if (p.out_mode == DFW_OUT_F32) {
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float v[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) v[o] = (acc[px][o] + bs[o]) * p.out_scale;
+      float* o2 = (float*)p.y + ((size_t)b * HW + pix + px) * p.ldy + co0;
+      *(f32x4*)o2 = f32x4{v[0], v[1], v[2], v[3]};
+      *(f32x4*)(o2 + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
   } else {
 #pragma unroll
@@ -219,6 +234,12 @@ __global__ __launch_bounds__(256) void conv_small8w_kernel(const CsP p) {
       for (int o = 0; o < 4; ++o) {
         v[2 * o] = (acc[px][o][0] + bs[oct * 8 + 2 * o]) * p.out_scale;
         v[2 * o + 1] = (acc[px][o][1] + bs[oct * 8 + 2 * o + 1]) * p.out_scale;
+      }
+      if (p.out_mode == DFW_OUT_F32) {      // NHWC fp32 (the fp32 residual stream): 16 lanes write 512-byte pixel rows
+        float* o2 = (float*)p.y + ((size_t)b * HW + pix + px) * p.ldy + cb0 + oct * 8;
+        *(f32x4*)o2 = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(o2 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        continue;
       }
       const i32x4 pk = pack8<T>(v);
       *(i32x4*)(p.y + (((size_t)b * HW + pix + px) * p.ldy + cb0 + oct * 8) * sizeof(T)) = pk;
@@ -356,6 +377,17 @@ __global__ __launch_bounds__(256) void concat_kernel(const i32x4* a, const i32x4
     const long long r = e / nch;
     const int c = (int)(e - r * nch);
     y[e] = c < cha ? a[r * cha + c] : b[r * chb + (c - cha)];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> storage dtype, 8 elements per thread (the 16-bit MFMA-operand copy of an fp32 residual-stream tensor).
+template <typename T>
+__global__ __launch_bounds__(256) void convert_f32_kernel(const float* x, char* y, long long n8) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n8; e += (long long)gridDim.x * 256) {
+    const f32x4 a = __builtin_nontemporal_load((const f32x4*)(x + e * 8)), b = __builtin_nontemporal_load((const f32x4*)(x + e * 8 + 4));
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    *(i32x4*)(y + e * 8 * sizeof(T)) = pack8<T>(f);
   }
 }
 
@@ -538,12 +570,12 @@ static long long cs8w_iters(const dfw_conv_small_args* a) {
   return iters < 1 ? 1 : (iters > 8 ? 8 : iters);
 }
 static bool cs8w_ok(const dfw_conv_small_args* a) {
-  return a->Wd % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_mode == DFW_OUT_T && a->Cout % 8 == 0 &&
+  return a->Wd % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && (a->out_mode == DFW_OUT_T || a->out_mode == DFW_OUT_F32) && a->Cout % 8 == 0 &&
          a->taps * a->Cin <= 72 && (a->taps == 9 || a->taps == 1);
 }
 
 extern "C" int32_t dfw_conv_small_gn_chunks(const dfw_conv_small_args* a) {
-  if (!a || a->gn_groups <= 0 || !cs8w_ok(a) || a->Cout % 128 != 0 || a->Cout % a->gn_groups != 0) return 0;
+  if (!a || a->gn_groups <= 0 || !cs8w_ok(a) || a->out_mode != DFW_OUT_T || a->Cout % 128 != 0 || a->Cout % a->gn_groups != 0) return 0;
   const int cpg = a->Cout / a->gn_groups;
   if (128 % cpg != 0) return 0;
   const long long per_img = (long long)a->H * (a->Wd / 8), per_blk = 16 * cs8w_iters(a);
@@ -555,8 +587,8 @@ extern "C" int dfw_conv_small(const dfw_conv_small_args* a, dfw_stream_t stream)
   if (!a || !a->x || !a->W || !a->y) return DFW_EINVAL;
   if (a->B <= 0 || a->H <= 0 || a->Wd <= 0 || a->Cout <= 0) return DFW_EINVAL;
   if (a->Cin <= 0 || a->Cin > 8 || (a->taps != 1 && a->taps != 9)) return DFW_ESHAPE;
-  if (a->out_mode == DFW_OUT_T && (a->Cout % 8 != 0 || a->ldy % 8 != 0)) return DFW_ESHAPE;
-  if (a->out_mode != DFW_OUT_T && a->out_mode != DFW_OUT_NCHW_F32) return DFW_ESHAPE;
+  if (a->out_mode != DFW_OUT_NCHW_F32 && (a->Cout % 8 != 0 || a->ldy % 8 != 0)) return DFW_ESHAPE;
+  if (a->out_mode != DFW_OUT_T && a->out_mode != DFW_OUT_F32 && a->out_mode != DFW_OUT_NCHW_F32) return DFW_ESHAPE;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   CsP p;
   p.x = a->x; p.W = a->W; p.bias = a->bias; p.y = (char*)a->y;
@@ -662,6 +694,19 @@ extern "C" int dfw_concat_channels(const void* a, const void* b, void* y, int64_
   return 0;
 }
 
+extern "C" int dfw_convert_f32(const float* x, void* y, int64_t n, int32_t dtype, dfw_stream_t stream) {
+  if (!x || !y || n <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  if (n % 8 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return DFW_ESHAPE;
+  const long long n8 = n / 8;
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((convert_f32_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (char*)y, n8);
+  else hipLaunchKernelGGL((convert_f32_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (char*)y, n8);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dfw_timestep_embedding(const float* timesteps, void* out, int32_t B, int32_t dim,
                                       int32_t flip_sin_to_cos, float freq_shift, int32_t dtype,
                                       dfw_stream_t stream) {
@@ -721,7 +766,41 @@ extern "C" int dfw_meter_update(const int64_t* counts, const int64_t* class_id, 
 }
 
 // ---------------------------------------------------------------------------------------------
-extern "C" int dfw_version(void) { return 101; }
+// Host-side inspection of a captured hipGraph_t: number of memset nodes (and the node count), recursing into child graphs.
+static int count_memset_nodes(hipGraph_t g, int32_t* total, int depth) {
+  size_t n = 0;
+  if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return -1;
+  if (n == 0) return 0;
+  hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(n * sizeof(hipGraphNode_t));
+  if (!nodes) return -1;
+  int cnt = 0;
+  if (hipGraphGetNodes(g, nodes, &n) != hipSuccess) { free(nodes); return -1; }
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) { free(nodes); return -1; }
+    if (total) ++*total;
+    if (t == hipGraphNodeTypeMemset) ++cnt;
+    else if (t == hipGraphNodeTypeGraph && depth < 4) {
+      hipGraph_t child;
+      if (hipGraphChildGraphNodeGetGraph(nodes[i], &child) == hipSuccess) {
+        const int c = count_memset_nodes(child, total, depth + 1);
+        if (c < 0) { free(nodes); return -1; }
+        cnt += c;
+      }
+    }
+  }
+  free(nodes);
+  return cnt;
+}
+
+extern "C" int dfw_graph_memset_nodes(void* graph, int32_t* n_nodes) {
+  if (!graph) return DFW_EINVAL;
+  if (n_nodes) *n_nodes = 0;
+  const int c = count_memset_nodes((hipGraph_t)graph, n_nodes, 0);
+  return c < 0 ? DFW_EINVAL : c;
+}
+
+extern "C" int dfw_version(void) { return 102; }
 
 extern "C" const char* dfw_error_string(int code) {
   switch (code) {

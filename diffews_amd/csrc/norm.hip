@@ -21,7 +21,28 @@ struct GnP {
   int rev;  // statistics / apply: walk images and pixel chunks back to front
 };
 
-template <typename T>
+// 8 consecutive channels of the input as floats: X = the storage type (one 16-byte load) or float (two) -- the
+// fp32 residual stream (residual_dtype=torch.float32) is normalised straight from fp32, so the stream itself is
+// never rounded to 16 bits; only this kernel's OUTPUT (an MFMA operand) is.
+template <typename X> struct In8 {
+  using raw = i32x4;
+  static __device__ __forceinline__ raw ld(const char* p) { return *(const i32x4*)p; }
+  static __device__ __forceinline__ raw ldnt(const char* p) { return __builtin_nontemporal_load((const i32x4*)p); }
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) { unpack8<X>(r, f); }
+};
+template <> struct In8<float> {
+  struct raw { f32x4 a, b; };
+  static __device__ __forceinline__ raw ld(const char* p) { return raw{*(const f32x4*)p, *(const f32x4*)(p + 16)}; }
+  static __device__ __forceinline__ raw ldnt(const char* p) {
+    return raw{__builtin_nontemporal_load((const f32x4*)p), __builtin_nontemporal_load((const f32x4*)(p + 16))};
+  }
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = r.a[i]; f[4 + i] = r.b[i]; }
+  }
+};
+
+template <typename T, typename X = T>
 __global__ void gn_stats_kernel(const GnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_n[];
   float* ls = (float*)smem_n;  // [slots][C][2]
@@ -36,23 +57,23 @@ __global__ void gn_stats_kernel(const GnP p) {
   float s[8], ss[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
-  const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
+  const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(X);
   int px = p0 + slot;
   for (; px + 3 * slots < p1; px += 4 * slots) {   // four loads in flight (same order of accumulation)
-    i32x4 raw[4];
+    typename In8<X>::raw raw[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) raw[u] = *(const i32x4*)(xb + (size_t)(px + u * slots) * p.ldx * sizeof(T));
+    for (int u = 0; u < 4; ++u) raw[u] = In8<X>::ld(xb + (size_t)(px + u * slots) * p.ldx * sizeof(X));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float f[8];
-      unpack8<T>(raw[u], f);
+      In8<X>::unpack(raw[u], f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s[i] += f[i]; ss[i] += f[i] * f[i]; }
     }
   }
   for (; px < p1; px += slots) {
     float f[8];
-    unpack8<T>(*(const i32x4*)(xb + (size_t)px * p.ldx * sizeof(T)), f);
+    In8<X>::unpack(In8<X>::ld(xb + (size_t)px * p.ldx * sizeof(X)), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] += f[i]; ss[i] += f[i] * f[i]; }
   }
@@ -119,7 +140,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
 }
 
 // Apply: thread = fixed 8 channels (scale/shift in registers), streams its pixel range.
-template <typename T>
+template <typename T, typename X = T>
 __global__ void gn_apply_kernel(const GnP p) {
   const int b = p.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int chunk = p.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
@@ -136,19 +157,19 @@ __global__ void gn_apply_kernel(const GnP p) {
     rs[i] = rstd * w;
     rh[i] = bb - mean * rs[i];
   }
-  const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(T);
+  const char* xb = p.x + ((size_t)b * p.HW * p.ldx + cc * 8) * sizeof(X);
   char* yb = p.y + ((size_t)b * p.HW * p.ldy + cc * 8) * sizeof(T);
   // four independent 16-byte loads in flight per thread: one load per iteration left the kernel
   // latency-bound at ~3.5 TB/s
   int px = p0 + slot;
   for (; px + 3 * slots < p1; px += 4 * slots) {
-    i32x4 raw[4];
+    typename In8<X>::raw raw[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load((const i32x4*)(xb + (size_t)(px + u * slots) * p.ldx * sizeof(T)));
+    for (int u = 0; u < 4; ++u) raw[u] = In8<X>::ldnt(xb + (size_t)(px + u * slots) * p.ldx * sizeof(X));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float f[8];
-      unpack8<T>(raw[u], f);
+      In8<X>::unpack(raw[u], f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float v = f[i] * rs[i] + rh[i];
@@ -160,7 +181,7 @@ __global__ void gn_apply_kernel(const GnP p) {
   }
   for (; px < p1; px += slots) {
     float f[8];
-    unpack8<T>(*(const i32x4*)(xb + (size_t)px * p.ldx * sizeof(T)), f);
+    In8<X>::unpack(In8<X>::ld(xb + (size_t)px * p.ldx * sizeof(X)), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float v = f[i] * rs[i] + rh[i];
@@ -178,20 +199,20 @@ struct LnP {
   float eps;
 };
 
-template <typename T, int MAXC>
+template <typename T, int MAXC, typename X = T>
 __global__ __launch_bounds__(256) void ln_kernel(const LnP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= p.rows) return;
   const int nch = p.C >> 3;
   float f[MAXC][8];
-  const char* xr = p.x + (size_t)row * p.ldx * sizeof(T);
+  const char* xr = p.x + (size_t)row * p.ldx * sizeof(X);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
-      unpack8<T>(*(const i32x4*)(xr + ch * 16), f[i]);
+      In8<X>::unpack(In8<X>::ld(xr + ch * 8 * sizeof(X)), f[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += f[i][j];
     }
@@ -290,7 +311,16 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   }
   GnP pa = p;  // apply pass keeps its own pixel chunking
   pa.chunks = chunks;
-  if (a->dtype == DFW_BF16) {
+  if (a->x_f32) {   // fp32 residual stream in, storage dtype out
+    if (!pre) hipLaunchKernelGGL((gn_stats_kernel<__bf16, float>), grid, dim3(threads), lds1, st, p);   // T unused by the statistics
+    DFW_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+    if (!coef_only) {
+      if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gn_apply_kernel<__bf16, float>), grid, dim3(threads), 0, st, pa);
+      else hipLaunchKernelGGL((gn_apply_kernel<_Float16, float>), grid, dim3(threads), 0, st, pa);
+    }
+  } else if (a->dtype == DFW_BF16) {
     if (!pre) hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
@@ -318,7 +348,12 @@ extern "C" int dfw_layernorm(const dfw_layernorm_args* a, dfw_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((a->rows + 3) / 4);
   const int nch = a->C / 8;
-  if (a->dtype == DFW_BF16) {
+  if (a->x_f32) {
+    const bool bf = a->dtype == DFW_BF16;
+    if (nch <= 64) { if (bf) hipLaunchKernelGGL((ln_kernel<__bf16, 1, float>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((ln_kernel<_Float16, 1, float>), grid, dim3(256), 0, st, p); }
+    else if (nch <= 128) { if (bf) hipLaunchKernelGGL((ln_kernel<__bf16, 2, float>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((ln_kernel<_Float16, 2, float>), grid, dim3(256), 0, st, p); }
+    else { if (bf) hipLaunchKernelGGL((ln_kernel<__bf16, 4, float>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((ln_kernel<_Float16, 4, float>), grid, dim3(256), 0, st, p); }
+  } else if (a->dtype == DFW_BF16) {
     if (nch <= 64) hipLaunchKernelGGL((ln_kernel<__bf16, 1>), grid, dim3(256), 0, st, p);
     else if (nch <= 128) hipLaunchKernelGGL((ln_kernel<__bf16, 2>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((ln_kernel<__bf16, 4>), grid, dim3(256), 0, st, p);

@@ -91,8 +91,9 @@ def linear(x, w, bias=None, residual=None, rowbias=None, rows_per_img=0, act=L.A
     a.bias = _p(_f32(bias, "bias"))
     _rowbias(a, rowbias)
     if residual is not None:
-        assert residual.dtype == x.dtype and residual.stride(1) == 1 and residual.shape == (M, N)
+        assert residual.dtype in (x.dtype, torch.float32) and residual.stride(1) == 1 and residual.shape == (M, N)
         a.residual, a.ldr = residual.data_ptr(), residual.stride(0)
+        a.residual_f32 = int(residual.dtype == torch.float32)   # the fp32 residual stream
     a.a_elems = (M - 1) * x.stride(0) + K
     a.w_elems = w.numel()
     a.M, a.N, a.K, a.lda, a.ldc = M, N, K, x.stride(0), out.stride(0)
@@ -129,20 +130,25 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
-            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, fuse_gn_in=None, act=L.ACT_NONE):
+            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, fuse_gn_in=None, act=L.ACT_NONE,
+            out_f32=False):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
     gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x -- applied
     by dfw_groupnorm first, or (fuse_gn_in=True, or DFW_GN_FUSE=1 in the environment) inside the conv
     kernel where the library supports that for the shape.  The fused form is off by default: measured
-    on MI355X it does not pay yet (conv_halo.hip)."""
+    on MI355X it does not pay yet (conv_patch.hip, GNIN).
+    out_f32: NHWC fp32 output, and `residual` may be fp32 -- the fp32 residual stream (x + branch summed and stored
+    in fp32; the conv's operands stay 16-bit)."""
     assert x.dim() == 4 and x.stride(3) == 1 and x.is_contiguous()
     B, Hi, Wi, Cin = x.shape
     if fuse_gn_in is None:
         fuse_gn_in = _GN_FUSE_DEFAULT
-    if gn_in is not None and not (fuse_gn_in and _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk)):
-        x = groupnorm(x, *gn_in)
+    if gn_in is not None and not (fuse_gn_in and not out_f32 and x.dtype != torch.float32
+                                  and (residual is None or residual.dtype == x.dtype)
+                                  and _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk)):
+        x = groupnorm(x, *gn_in, out_dtype=w.dtype)
         gn_in = None
     assert w.shape == (cout, 9 * Cin) and w.dtype == x.dtype and w.is_contiguous()
     if ups:
@@ -156,21 +162,22 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     if out_nchw_f32:
         out = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device)
     else:
-        out = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
+        out = torch.empty(B, Ho, Wo, cout, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     a = L.GemmArgs()
     a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     a.bias = _p(_f32(bias, "bias"))
     _rowbias(a, rowbias)
     if residual is not None:
-        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == M * cout
+        assert residual.dtype in (x.dtype, torch.float32) and residual.is_contiguous() and residual.numel() == M * cout
         a.residual, a.ldr = residual.data_ptr(), cout
+        a.residual_f32 = int(residual.dtype == torch.float32)
     a.a_elems, a.w_elems = x.numel(), w.numel()
     a.M, a.N, a.K, a.lda, a.ldc = M, cout, 9 * Cin, Cin, cout
     a.taps, a.Cin, a.Hi, a.Wi, a.Ho, a.Wo = 9, Cin, Hi, Wi, Ho, Wo
     a.stride, a.pad, a.ups = stride, pad, int(ups)
     a.rows_per_img = Ho * Wo
     a.out_scale, a.act = out_scale, act
-    a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else L.OUT_T
+    a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else (L.OUT_F32 if out_f32 else L.OUT_T)
     a.splitk = 0 if splitk is None else splitk
     a.batch, a.dtype = 1, _dt(x)
     if gn_in is not None:
@@ -278,10 +285,15 @@ def groupnorm_coeff(x, gamma, beta, groups, eps):
     return groupnorm(x, gamma, beta, groups, eps, _coef_only=True)
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_stats=False):
+def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_stats=False, out_dtype=None):
     """GroupNorm (+SiLU) over NHWC x [B, H, W, C] (or [B, HW, C]).
-    return_stats: also return the (mean, rstd) [B, groups, 2] fp32 the kernel normalised with (training)."""
+    return_stats: also return the (mean, rstd) [B, groups, 2] fp32 the kernel normalised with (training).
+    x may be fp32 (the fp32 residual stream): the output is then `out_dtype` (bf16 / fp16, required)."""
     assert x.is_contiguous()
+    xf32 = x.dtype == torch.float32
+    if xf32 and out_dtype not in _DT:
+        raise TypeError("groupnorm of an fp32 tensor needs out_dtype=torch.bfloat16 / torch.float16")
+    odt = out_dtype if xf32 else x.dtype
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
     a = L.GroupNormArgs()
@@ -290,10 +302,10 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_
         a.coef_out = y.data_ptr()
         a.x, a.gamma, a.beta = x.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
     else:
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=odt, device=x.device)
         a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
     a.B, a.HW, a.C, a.groups, a.ldx, a.ldy = B, HW, Cc, groups, Cc, Cc
-    a.eps, a.silu, a.dtype = eps, int(silu), _dt(x)
+    a.eps, a.silu, a.dtype, a.x_f32 = eps, int(silu), _DT[odt], int(xf32)
     st = getattr(x, "_gn_stats", None)
     if st is not None and st[2] == groups and st[0].shape[0] == B:
         a.pre_partial, a.pre_chunks = st[0].data_ptr(), st[1]
@@ -309,18 +321,24 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_
     return y
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
+    """x may be fp32 (the fp32 residual stream inside a transformer block): the output is then `out_dtype`."""
     assert x.dim() == 2 and x.stride(1) == 1
-    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    xf32 = x.dtype == torch.float32
+    if xf32 and out_dtype not in _DT:
+        raise TypeError("layernorm of an fp32 tensor needs out_dtype=torch.bfloat16 / torch.float16")
+    odt = out_dtype if xf32 else x.dtype
+    y = torch.empty(x.shape, dtype=odt, device=x.device)
     a = L.LayerNormArgs()
     a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
-    a.rows, a.C, a.ldx, a.ldy, a.eps, a.dtype = x.shape[0], x.shape[1], x.stride(0), y.stride(0), eps, _dt(x)
+    a.rows, a.C, a.ldx, a.ldy, a.eps, a.dtype = x.shape[0], x.shape[1], x.stride(0), y.stride(0), eps, _DT[odt]
+    a.x_f32 = int(xf32)
     L.check(L.lib().dfw_layernorm(C.byref(a), _stream()), "dfw_layernorm")
     return y
 
 
 def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, out_scale=1.0, gn_groups=0,
-               out=None, gn_part=None):
+               out=None, gn_part=None, out_f32=False):
     """Boundary conv with Cin <= 8: x NCHW fp32 [B, Cin, H, W], w fp32 [Cout, taps, Cin].
     gn_groups: also emit the GroupNorm partial sums of the output where the kernel supports it (y._gn_stats).
     x may be a list/tuple of up to three such tensors (same Cin, H, W): the batch is their concatenation,
@@ -348,16 +366,17 @@ def conv_small(x, w, bias, cout, taps, dtype, nchw_f32_out=False, in_scale=1.0, 
         assert y.shape == (B, cout, H, W) and y.dtype == torch.float32
         assert y.stride(3) == 1 and y.stride(2) == W and y.stride(1) == H * W
         a.y_bstride = y.stride(0) if B > 1 else cout * H * W
-    else:
-        y = out if out is not None else torch.empty(B, H, W, cout, dtype=dtype, device=x.device)
-        assert y.shape == (B, H, W, cout) and y.dtype == dtype and y.is_contiguous()
+    else:   # NHWC: storage dtype, or fp32 (out_f32: the fp32 residual stream starts at conv_in)
+        ydt = torch.float32 if out_f32 else dtype
+        y = out if out is not None else torch.empty(B, H, W, cout, dtype=ydt, device=x.device)
+        assert y.shape == (B, H, W, cout) and y.dtype == ydt and y.is_contiguous()
     a.x, a.W, a.bias, a.y = x.data_ptr(), w.data_ptr(), _p(_f32(bias, "bias")), y.data_ptr()
     a.B, a.Cin, a.H, a.Wd, a.Cout, a.taps, a.ldy = B, Cin, H, W, cout, taps, cout
     a.in_scale, a.out_scale = in_scale, out_scale
-    a.out_mode = L.OUT_NCHW_F32 if nchw_f32_out else L.OUT_T
+    a.out_mode = L.OUT_NCHW_F32 if nchw_f32_out else (L.OUT_F32 if out_f32 else L.OUT_T)
     a.dtype = _DT[dtype]
     stats = None
-    if gn_groups and not nchw_f32_out:
+    if gn_groups and not nchw_f32_out and not out_f32:
         a.gn_groups = gn_groups
         chunks = L.lib().dfw_conv_small_gn_chunks(C.byref(a))
         if chunks > 0:
@@ -422,8 +441,23 @@ def concat_channels(a, b):
     Ca, Cb = a.shape[-1], b.shape[-1]
     y = torch.empty(*a.shape[:-1], Ca + Cb, dtype=a.dtype, device=a.device)
     rows = a.numel() // Ca
+    if a.dtype == torch.float32:   # fp32 residual stream: a byte copy -- C fp32 channels are 2C 16-bit units to the kernel
+        L.check(L.lib().dfw_concat_channels(a.data_ptr(), b.data_ptr(), y.data_ptr(), rows, 2 * Ca, 2 * Cb, L.BF16, _stream()),
+                "dfw_concat_channels")
+        return y
     L.check(L.lib().dfw_concat_channels(a.data_ptr(), b.data_ptr(), y.data_ptr(), rows, Ca, Cb, _dt(a), _stream()),
             "dfw_concat_channels")
+    return y
+
+
+def to_storage(x, dtype):
+    """fp32 -> storage dtype copy (the 16-bit MFMA-operand view of an fp32 residual-stream tensor); identity for a
+    tensor that already is `dtype`."""
+    if x.dtype == dtype:
+        return x
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 8 == 0
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().dfw_convert_f32(x.data_ptr(), y.data_ptr(), x.numel(), _DT[dtype], _stream()), "dfw_convert_f32")
     return y
 
 

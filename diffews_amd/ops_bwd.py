@@ -212,6 +212,15 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     if nbytes:      # dQ key split of the bank readers (many shots)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    from . import ops as _ops
+    if _ops.gemm_hook is not None:      # bench.py roofline leg: the dQ + dK/dV kernels of this launch (5 GEMMs = 2.5 x the forward's 2)
+        keys = n_plain * N + (B - n_plain) * (N + nshot * N)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.dfw_fsa_attention_bwd(C.byref(a), _stream()), "dfw_fsa_attention_bwd")
+        e1.record()
+        _ops.gemm_hook("fsa_attention_bwd", 10.0 * heads * 64 * N * keys, e0, e1, (B, heads, N, keys))
+        return dqkv
     L.check(lib.dfw_fsa_attention_bwd(C.byref(a), _stream()), "dfw_fsa_attention_bwd")
     return dqkv
 
@@ -326,8 +335,29 @@ def weight_relayout_batch(table):
     L.check(L.lib().dfw_weight_relayout_batch(t.data_ptr(), n, blocks, _stream()), "dfw_weight_relayout_batch")
 
 
+def loss_grad(g, dtype, scale=1.0, dpred_out=None, dpred_nchw_out=None):
+    """External d loss / d pred (NCHW fp32 [B, C, H, W]) -> the same two tensors mse_loss hands the backward:
+    dpred NHWC [B, H, W, 8] in `dtype` = round(g * scale) (channels C..7 untouched) and its NCHW fp32 copy."""
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.dim() == 4
+    B, Cc, H, W = g.shape
+    dpred = dpred_out if dpred_out is not None else torch.zeros(B, H, W, 8, dtype=dtype, device=g.device)
+    assert dpred.shape == (B, H, W, 8) and dpred.is_contiguous() and dpred.dtype == dtype
+    if dpred_nchw_out is not None:
+        assert dpred_nchw_out.shape == g.shape and dpred_nchw_out.is_contiguous() and dpred_nchw_out.dtype == torch.float32
+    L.check(L.lib().dfw_loss_grad(g.data_ptr(), dpred.data_ptr(), _p(dpred_nchw_out), B, Cc, H * W, float(scale),
+                                  L.BF16 if dtype == torch.bfloat16 else L.F16, _stream()), "dfw_loss_grad")
+    return dpred
+
+
+def to_f32(x, out, scale=1.0):
+    """out (fp32) = x (storage dtype) * scale, flat contiguous buffers."""
+    assert out.dtype == torch.float32 and out.is_contiguous() and x.is_contiguous() and x.numel() == out.numel()
+    L.check(L.lib().dfw_convert_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), float(scale), _dt(x), _stream()), "dfw_convert_to_f32")
+    return out
+
+
 def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_sumsq=None,
-          max_grad_norm=0.0, shadow=None):
+          max_grad_norm=0.0, shadow=None, found_inf=None):
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
     a = L.AdamWArgs()
@@ -335,6 +365,9 @@ def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e
     a.grad_sumsq = _p(grad_sumsq)
     a.n, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = param.numel(), lr, betas[0], betas[1], eps, weight_decay
     a.max_grad_norm, a.step = max_grad_norm, step
+    if found_inf is not None:
+        assert found_inf.dtype == torch.int32 and found_inf.numel() >= 1
+        a.found_inf = found_inf.data_ptr()
     if shadow is not None:
         assert shadow.numel() == param.numel() and shadow.is_contiguous()
         a.shadow, a.shadow_dtype = shadow.data_ptr(), _dt(shadow)

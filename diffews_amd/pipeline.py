@@ -61,6 +61,24 @@ def load_empty_text_embed(checkpoint, tokenizer=None):
         return enc(ids)[0].float()
 
 
+def _assert_no_memset_nodes(graph):
+    """Invariant of the captured step: no memset node.  On ROCm 7.2 a small memset node replayed
+    next to plain launches on the same stream received the following launch's kernel arguments (all-zero predictions in
+    the bench metric); the library therefore zeroes its scratch words with kernels.  A torch.zeros / .zero_() / fill_ that
+    slips into the step later would re-introduce such a node silently, so every capture is inspected once
+    (dfw_graph_memset_nodes walks the hipGraph_t's nodes).  Returns the node count."""
+    import ctypes as C
+    from . import _lib as L
+    n = C.c_int32(0)
+    rc = L.lib().dfw_graph_memset_nodes(C.c_void_p(graph.raw_cuda_graph()), C.byref(n))
+    if rc < 0:
+        L.check(rc, "dfw_graph_memset_nodes")
+    if rc > 0:
+        raise RuntimeError(f"the captured step contains {rc} memset node(s) (torch.zeros / zero_ / fill_ inside the step?): "
+                           "zero scratch with a library kernel instead, see DESIGN.md section 2")
+    return n.value
+
+
 class MarigoldPipelineRGBLatentNoise:
     rgb_latent_scale_factor = 0.18215   # P:120-124
     seg_latent_scale_factor = 0.18215
@@ -86,7 +104,7 @@ class MarigoldPipelineRGBLatentNoise:
     @classmethod
     def from_pretrained(cls, checkpoint=None, unet=None, vae=None, scheduler=None, tokenizer=None, text_embeds=None,
                         text_encoder=None, controlnet=None, image_projector=None, customized_head=None,
-                        image_encoder=None, torch_dtype=None, **kw):
+                        image_encoder=None, torch_dtype=None, residual_dtype=None, **kw):
         from .unet import MyUNet2DConditionModel
         from .vae import AutoencoderKL
         dt = torch_dtype or torch.bfloat16
@@ -96,9 +114,9 @@ class MarigoldPipelineRGBLatentNoise:
             # The prompt is a per-checkpoint constant: evaluate it ONCE here (host, fp32) and keep the result.
             text_embeds = load_empty_text_embed(checkpoint, tokenizer)
         if unet is None:
-            unet = MyUNet2DConditionModel.from_pretrained(checkpoint, subfolder="unet", torch_dtype=dt)
+            unet = MyUNet2DConditionModel.from_pretrained(checkpoint, subfolder="unet", torch_dtype=dt, residual_dtype=residual_dtype)
         if vae is None:
-            vae = AutoencoderKL.from_pretrained(checkpoint, subfolder="vae", torch_dtype=dt)
+            vae = AutoencoderKL.from_pretrained(checkpoint, subfolder="vae", torch_dtype=dt, residual_dtype=residual_dtype)
         if scheduler is None:
             scheduler = DDIMSchedulerCustomized.from_pretrained(checkpoint, subfolder="scheduler")
         return cls(unet, vae, scheduler, tokenizer=tokenizer, text_embeds=text_embeds, text_encoder=text_encoder,
@@ -114,6 +132,25 @@ class MarigoldPipelineRGBLatentNoise:
 
     def enable_xformers_memory_efficient_attention(self, *a, **k):
         return None
+
+    @property
+    def residual_dtype(self):
+        return self.unet.residual_dtype
+
+    def set_residual_dtype(self, residual_dtype=None, vae_residual_dtype="same"):
+        """Storage of the residual stream of the UNet and the VAE: None = the engines' storage dtype (fastest),
+        torch.float32 = fp32 stream with 16-bit MFMA operands (north_star's 1e-3 in fp16).  The
+        weights are shared by both modes (only epilogue flags differ), so this is a switch, not a rebuild; captured
+        graphs are dropped."""
+        rd = residual_dtype or self.unet.dtype
+        vd = rd if vae_residual_dtype == "same" else (vae_residual_dtype or self.vae.dtype)
+        if rd not in (self.unet.dtype, torch.float32) or vd not in (self.vae.dtype, torch.float32):
+            raise ValueError("residual_dtype must be None (= storage dtype) or torch.float32")
+        self.unet.residual_dtype, self.unet._f32s = rd, rd == torch.float32
+        self.vae.residual_dtype = vd
+        self.vae.encoder.f32s = self.vae.decoder.f32s = vd == torch.float32
+        self._graphs = {}
+        return self
 
     def encode_clip_feature(self, clip_rgb_in=None):
         """P:585-601; evaluated once, the prompt is the constant ""."""
@@ -221,7 +258,7 @@ class MarigoldPipelineRGBLatentNoise:
         if not captured:
             return step(**ins)
         key = (tuple(ins["support_imgs"].shape), tuple(ins["query_img"].shape), query_gt is not None, flags,
-               float(tt), folded, getattr(self, "_fold_key", None))
+               float(tt), folded, getattr(self, "_fold_key", None), self.unet.residual_dtype, self.vae.residual_dtype)
         return self._replay(key, step, ins)
 
     def _episodes_step(self, support_imgs, query_img, support_masks, query_gt, tt, folded, flags):
@@ -266,9 +303,15 @@ class MarigoldPipelineRGBLatentNoise:
                 step(**static_in)
             cur.wait_stream(side)
             torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            graph = torch.cuda.CUDAGraph(keep_graph=True)   # keep the hipGraph_t for the node-type check below
+            # thread_local: other host threads (the EpisodeLoader's producer allocates first-use slots and pinned
+            # buffers and synchronises its copy events while this thread captures) must neither fail nor invalidate
+            # the capture -- the default 'global' mode turns any hipMalloc / hipHostMalloc / event sync of ANY thread
+            # into hipErrorStreamCaptureUnsupported
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = step(**static_in)
+            self.graph_nodes = _assert_no_memset_nodes(graph)
+            graph.instantiate()
             ent = (graph, static_in, out)
             self._graphs[key] = ent
         graph, static_in, out = ent

@@ -47,12 +47,16 @@ class _Tape:
         have = self.g.get(k)
         self.g[k] = g if have is None else ob.add(have, g.reshape(have.shape))
 
-    def backward(self, out, dout):
+    def backward(self, out, dout, after=None):
+        """after: called once after every closure that ran (the overlapped gradient all-reduce looks there for parameter
+        gradients that just became final)."""
         self.accum(out, dout)
         for o, fn in reversed(self.ops):
             g = self.g.pop(self._key(o), None)
             if g is not None:
                 fn(g.reshape(o.shape))
+                if after is not None:
+                    after()
         self.ops, self.g = [], {}
 
 
@@ -70,16 +74,23 @@ class ParamStore:
         self._init.append((self.numel, t))
         self.numel += n
 
+    TAIL = 64   # floats behind the last parameter gradient: slot 0 carries the step's loss through the last gradient bucket
+
     def finalize(self):
         self.master = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         for off, t in self._init:
             self.master[off:off + t.numel()].copy_(t.reshape(-1))
         self._init = None
-        self.grad = torch.zeros_like(self.master)
+        # gradient buffer + TAIL: `grad` (what the optimizer, the norm and the exports see) is the first numel floats; the
+        # collective's last bucket extends over the tail, so the scalar loss is averaged over the ranks with it (T:1387)
+        self.grad_buf = torch.zeros(self.numel + self.TAIL, dtype=torch.float32, device=self.device)
+        self.grad = self.grad_buf[:self.numel]
         self.exp_avg = torch.zeros_like(self.master)
         self.exp_avg_sq = torch.zeros_like(self.master)
-        self.shadow = self.master.to(self.dtype)
-        self.version = 0
+        self.shadow = torch.empty(self.numel, dtype=self.dtype, device=self.device)
+        self.version = -1
+        self.sync_shadow()
+        self._written, self._new = set(), []
 
     def _view(self, buf, name):
         off, shape = self.spec[name]
@@ -102,15 +113,27 @@ class ParamStore:
     # entries are never written and keep their zeros; entries nobody touched are zeroed at the end of the step.
     def begin_step(self, fresh):
         self._touched = set() if fresh else None
+        self._written, self._new = set(), []
 
     def acc(self, *names):
-        """accumulate flag for a kernel about to write these gradients (all or none must have been written before)."""
+        """accumulate flag for a kernel about to write these gradients (all or none must have been written before).
+        Every parameter's gradient is written by exactly ONE launch per micro-step, so a name that passes here is final
+        for this micro-step once that launch has been issued (pop_written: the overlapped all-reduce's readiness signal)."""
+        for n in names:
+            if n not in self._written:
+                self._written.add(n)
+                self._new.append(n)
         if getattr(self, "_touched", None) is None:
             return True
         seen = [n in self._touched for n in names]
         assert all(seen) or not any(seen), names
         self._touched.update(names)
         return seen[0]
+
+    def pop_written(self):
+        """Names whose gradient launch has been issued since the last call."""
+        out, self._new = self._new, []
+        return out
 
     def finish_step(self):
         if getattr(self, "_touched", None) is None:
@@ -121,7 +144,13 @@ class ParamStore:
         self._touched = None
 
     def sync_shadow(self):
-        self.shadow.copy_(self.master)
+        """16-bit shadow <- fp32 master (library kernel; after an external optimizer wrote the master)."""
+        if self.master.is_cuda:
+            L.check(L.lib().dfw_convert_f32(self.master.data_ptr(), self.shadow.data_ptr(), self.numel,
+                                            L.BF16 if self.dtype == torch.bfloat16 else L.F16,
+                                            torch.cuda.current_stream().cuda_stream), "dfw_convert_f32")
+        else:
+            self.shadow.copy_(self.master)
         self.version += 1
 
 
@@ -130,7 +159,8 @@ class UNetTrainer:
     (T:1105, 1136, 1163, 1189, 1376-1379): train(), parameters(), enable_gradient_checkpointing(),
     clear_attn_bank(), save_pretrained(), state_dict()."""
 
-    def __init__(self, config, state_dict, torch_dtype=torch.bfloat16, device="cuda", loss_scale=1.0):
+    def __init__(self, config, state_dict, torch_dtype=torch.bfloat16, device="cuda", loss_scale=1.0,
+                 dynamic_loss_scale=None, growth_interval=2000):
         cfg = weights.default_unet_config()
         cfg.update(config or {})
         self.config = cfg
@@ -138,6 +168,11 @@ class UNetTrainer:
         L.lib()
         weights.check_state_dict(state_dict, weights.unet_param_shapes(cfg), "unet")
         self.loss_scale = float(loss_scale)
+        # fp16: GradScaler's dynamic scale (halve on overflow, double after growth_interval clean steps); bf16 needs none
+        self.dynamic_loss_scale = (torch_dtype == torch.float16) if dynamic_loss_scale is None else bool(dynamic_loss_scale)
+        self.growth_interval, self._good_steps, self.skipped_steps = int(growth_interval), 0, 0
+        self._overflow_pending = None
+        self._param, self._master_seen, self._pending_ref, self.reducer = None, 0, None, None
         self.training = True
         self.step_count = 0
         self._derived, self._derived_version, self._derived_table = {}, -1, None
@@ -167,9 +202,17 @@ class UNetTrainer:
 
     def _build(self, sd):
         cfg = self.config
-        P = ParamStore(self.device, self.dtype)
-        self.P = P
+        real = ParamStore(self.device, self.dtype)
+        self.P = real
         f = lambda k: sd[k].float()
+
+        class _Pend:       # collect (name -> tensor) first; the flat layout is laid out in FORWARD order below
+            def __init__(self):
+                self.items = {}
+
+            def add(self, name, t):
+                self.items[name] = t
+        P = _Pend()
         P.add("conv_in.weight", packing.pack_conv_small(sd["conv_in.weight"]))
         P.add("conv_in.bias", f("conv_in.bias"))
         P.add("conv_in_ref.weight", packing.pack_conv_small(sd["conv_in_ref.weight"]))
@@ -235,9 +278,37 @@ class UNetTrainer:
         wo = packing.pack_conv3x3(f("conv_out.weight"))
         P.add("conv_out.weight", torch.cat([wo, torch.zeros(8 - wo.shape[0], wo.shape[1])], 0))
         P.add("conv_out.bias", torch.cat([f("conv_out.bias"), torch.zeros(8 - wo.shape[0])], 0))
+        # Flat layout = the order the forward USES the parameters, so the backward finishes their gradients from the END of
+        # the buffer towards its start: contiguous buckets complete one after the other and the gradient all-reduce of a
+        # bucket is issued while the backward of the earlier layers still runs (GradBucketReducer; DDP's overlap, T:1226-1228).
+        nb, lpb = len(boc), cfg["layers_per_block"]
+        order = ["time_embedding.linear_1.", "time_embedding.linear_2.", "tp_w", "tp_b", "kv_w_all", "conv_in_ref.", "conv_in."]
+        for i, typ in enumerate(cfg["down_block_types"]):
+            for j in range(lpb):
+                order.append(f"down_blocks.{i}.resnets.{j}.")
+                if typ == "CrossAttnDownBlock2D":
+                    order.append(f"down_blocks.{i}.attentions.{j}.")
+            order.append(f"down_blocks.{i}.downsamplers.0.conv.")
+        order += ["mid_block.resnets.0.", "mid_block.attentions.0.", "mid_block.resnets.1."]
+        for i, typ in enumerate(cfg["up_block_types"]):
+            for j in range(lpb + 1):
+                order.append(f"up_blocks.{i}.resnets.{j}.")
+                if typ == "CrossAttnUpBlock2D":
+                    order.append(f"up_blocks.{i}.attentions.{j}.")
+            order.append(f"up_blocks.{i}.upsamplers.0.conv.")
+        order += ["conv_norm_out.", "conv_out."]
+        left = dict(P.items)
+        for pre in order:
+            for name in [n for n in left if n.startswith(pre)]:
+                real.add(name, left.pop(name))
+        assert not left, sorted(left)
+        P = real
         P.finalize()
         self.groups, self.eps = cfg["norm_num_groups"], cfg["norm_eps"]
         self.heads_by_level = heads
+        if P.master.is_cuda:
+            self._found_inf = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._found_host = torch.zeros(1, dtype=torch.int32).pin_memory()
 
     # ------------------------------------------------------------------ boundary surface of the training launcher
     def train(self, mode=True):
@@ -266,8 +337,15 @@ class UNetTrainer:
         return self
 
     def parameters(self):
-        """The flat fp32 master buffer (one tensor): what the optimizer and the gradient all-reduce operate on."""
-        return [self.P.master]
+        """ONE torch.nn.Parameter over the flat fp32 master buffer (packed layout): what `torch.optim.AdamW(unet.parameters())`
+        (T:1186-1194), `clip_grad_norm_(unet.parameters(), ...)` (T:1393) and the gradient all-reduce operate on.  Its
+        `.grad` is the flat fp32 gradient (a view of P.grad) after a backward, None after optimizer.zero_grad().  An
+        in-place update by an external optimizer is noticed through the tensor's version counter and the 16-bit shadow
+        the kernels read is refreshed before the next forward."""
+        if self._param is None:
+            self._param = torch.nn.Parameter(self.P.master, requires_grad=True)
+            self._master_seen = self._param._version
+        return [self._param]
 
     def export(self, flat):
         """flat packed buffer (master or grad) -> dict in the diffusers key layout."""
@@ -480,12 +558,21 @@ class UNetTrainer:
         return out.view(B, H, W, C)
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self, z_refcat, z_tag, target, timestep, ehs, zero_grad=True):
-        """One micro-step: lock-step forward over [support ; query] latents, MSE(pred, target), backward.
-        z_refcat [b*s, 8, h, w] (cat([z_ref, z_mask_ref], 1), T:1360-1362), z_tag [b, 4, h, w], target [b, 4, h, w]
-        (= -z_mask_tag, T:1371), all fp32 NCHW; ehs [1, L, D] or [b, L, D] prompt embedding (T:1368).
-        Returns (loss fp32 tensor [1], pred [b, 4, h, w] fp32).  Gradients accumulate into P.grad (fp32, packed)."""
+    def _timestep_rows(self, timestep, Bt):
+        """[Bt] fp32 device vector of the step's timestep (T:1365 passes a cuda LongTensor [bsz]; no host sync here)."""
+        if torch.is_tensor(timestep):
+            return timestep.to(device=self.device, dtype=torch.float32).reshape(-1)[:1].expand(Bt).contiguous()
+        return torch.full((Bt,), float(timestep), dtype=torch.float32, device=self.device)
+
+    def _forward(self, z_refcat, z_tag, timestep, ehs, zero_grad=True, ehs_ref=None):
+        """Lock-step forward over [support ; query] latents with the backward tape.  Returns the context _backward needs;
+        ctx['pred'] is the query rows' prediction [b, 4, h, w] fp32 (the support pass' output is discarded, T:1381)."""
         P, dt, dev, cfg = self.P, self.dtype, self.device, self.config
+        if self.dynamic_loss_scale:      # the scale this step's kernels use depends on the previous step's overflow flag
+            self._resolve_overflow()
+        if self._param is not None and self._param._version != self._master_seen:
+            P.sync_shadow()              # an external optimizer (torch.optim.AdamW on parameters()) rewrote the master in place
+            self._master_seen = self._param._version
         tape = _Tape()
         gs = 1.0 / self.loss_scale
         P.begin_step(fresh=zero_grad)
@@ -495,7 +582,7 @@ class UNetTrainer:
         Bt = n_ref + bq
         c0 = cfg["block_out_channels"][0]
         # ---- time embedding (U:991-1015) and the 22 fused time projections
-        t = torch.full((Bt,), float(timestep), dtype=torch.float32, device=dev)
+        t = self._timestep_rows(timestep, Bt)
         temb = ops.timestep_embedding(t, c0, dt, cfg["flip_sin_to_cos"], float(cfg["freq_shift"]))
         e1 = self._linear(tape, temb, "time_embedding.linear_1.weight", "time_embedding.linear_1.bias", need_dx=False)
         a1 = ob.silu(e1)
@@ -516,7 +603,16 @@ class UNetTrainer:
         # ---- prompt K/V of all layers in one GEMM
         e = ehs.to(dev, dt)
         if e.shape[0] == 1:
-            e = e.expand(Bt, -1, -1)
+            e = e.expand(bq, -1, -1)
+        if ehs_ref is not None:          # the launcher's own rows for the support images (T:1369: the same prompt, repeated)
+            er = ehs_ref.to(dev, dt)
+            if er.shape[0] == 1:
+                er = er.expand(n_ref, -1, -1)
+            e = torch.cat([er, e], 0) if n_ref else e
+        elif e.shape[0] != Bt:
+            e = e[:1].expand(Bt, -1, -1)
+        if e.shape[0] != Bt:
+            raise ValueError(f"encoder_hidden_states rows {e.shape[0]} do not match the {Bt} latents of the step")
         L_ctx = e.shape[1]
         ehs2d = e.reshape(Bt * L_ctx, e.shape[2]).contiguous()
         kv_all = ops.linear(ehs2d, P.w("kv_w_all"))
@@ -578,37 +674,213 @@ class UNetTrainer:
         hn = self._gn(tape, x, "conv_norm_out.weight", "conv_norm_out.bias", self.eps, True)
         oc = cfg["out_channels"]
         pred_all = ops.conv3x3(hn, P.w("conv_out.weight")[:oc], oc, bias=P.p("conv_out.bias")[:oc], out_nchw_f32=True)
-        pred = pred_all[n_ref:]                                   # the support pass' output is discarded (T:1381)
-        # ---- loss (T:1384) and its gradient
-        tgt = target.to(dev, torch.float32).contiguous()
-        dpred = torch.zeros(Bt, h, w, 8, dtype=dt, device=dev)       # support rows: zero gradient (pred_ref * 0, T:1381)
+        # gradient seeds of conv_out: support rows stay zero (pred_ref * 0, T:1381).  torch.zeros here is deliberate: the
+        # training step is not captured by the pipeline's inference graph (see _assert_no_memset_nodes there)
+        dpred = torch.zeros(Bt, h, w, 8, dtype=dt, device=dev)
         dpn = torch.zeros(Bt, oc, h, w, dtype=torch.float32, device=dev)
-        loss, _ = ob.mse_loss(pred, tgt, dt, loss_scale=self.loss_scale, dpred_out=dpred[n_ref:], dpred_nchw_out=dpn[n_ref:])
+        return dict(tape=tape, hn=hn, pred_all=pred_all, pred=pred_all[n_ref:], n_ref=n_ref, h=h, w=w, c0=c0, oc=oc,
+                    tproj=tproj, dtproj=dtproj, kv_all=kv_all, dkv_all=dkv_all, dpred=dpred, dpn=dpn)
+
+    def _backward(self, c, reducer=None):
+        """Backward of _forward's graph from the loss gradient already deposited in c['dpred'] (NHWC, 8 channels, storage
+        dtype, times the loss scale) / c['dpn'] (the same rounded values, NCHW fp32).  Parameter gradients land in P.grad.
+        reducer: a GradBucketReducer -- told after every closure which parameter gradients have just been issued, so a
+        bucket's all-reduce starts as soon as its last writer is in the stream."""
+        P, dt, gs = self.P, self.dtype, 1.0 / self.loss_scale
+        tape, hn, h, w, c0, oc = c["tape"], c["hn"], c["h"], c["w"], c["c0"], c["oc"]
+        note = (lambda: reducer.mark(P.pop_written())) if reducer is not None else None
         # conv_out backward: weight / bias gradients in place (padded to 8 rows), data gradient by the direct conv
-        ob.gemm_tn(dpred, hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=P.acc("conv_out.weight"), scale=gs)
-        ob.colsum(dpred, out=P.g("conv_out.bias").view(1, 8), accumulate=P.acc("conv_out.bias"), scale=gs)
+        ob.gemm_tn(c["dpred"], hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=P.acc("conv_out.weight"), scale=gs)
+        ob.colsum(c["dpred"], out=P.g("conv_out.bias").view(1, 8), accumulate=P.acc("conv_out.bias"), scale=gs)
         wdo = P.p("conv_out.weight")[:oc].view(oc, 9, c0).flip(1).permute(2, 1, 0).contiguous()     # [c0][tap'][oc] fp32
-        dhn = ops.conv_small(dpn, wdo, None, c0, 9, dt)
-        tape.accum(tproj, dtproj)        # seeds of the two conditioning paths: their buffers fill up during the walk
-        tape.accum(kv_all, dkv_all)
-        tape.backward(hn, dhn)
+        dhn = ops.conv_small(c["dpn"], wdo, None, c0, 9, dt)
+        if note:
+            note()
+        tape.accum(c["tproj"], c["dtproj"])   # seeds of the two conditioning paths: their buffers fill up during the walk
+        tape.accum(c["kv_all"], c["dkv_all"])
+        tape.backward(hn, dhn, after=note)
         P.finish_step()
+        if note:
+            note()
         self._freeze_derived()
-        return loss, pred
+
+    def forward_backward(self, z_refcat, z_tag, target, timestep, ehs, zero_grad=True, reducer=None):
+        """One micro-step: lock-step forward over [support ; query] latents, MSE(pred, target), backward.
+        z_refcat [b*s, 8, h, w] (cat([z_ref, z_mask_ref], 1), T:1360-1362), z_tag [b, 4, h, w], target [b, 4, h, w]
+        (= -z_mask_tag, T:1371), all fp32 NCHW; ehs [1, L, D] or [b, L, D] prompt embedding (T:1368).
+        Returns (loss fp32 tensor [1], pred [b, 4, h, w] fp32).  Gradients accumulate into P.grad (fp32, packed).
+        reducer (GradBucketReducer): all-reduce the gradient buckets over the ranks WHILE the backward runs; the loss is
+        averaged with the last bucket (reducer.finish() returns it)."""
+        c = self._forward(z_refcat, z_tag, timestep, ehs, zero_grad)
+        n_ref = c["n_ref"]
+        tgt = target.to(self.device, torch.float32).contiguous()
+        loss, _ = ob.mse_loss(c["pred"], tgt, self.dtype, loss_scale=self.loss_scale, dpred_out=c["dpred"][n_ref:],
+                              dpred_nchw_out=c["dpn"][n_ref:])
+        if reducer is not None:
+            reducer.begin(loss)
+        self._backward(c, reducer)
+        return loss, c["pred"]
+
+    # ------------------------------------------------------------------ the reference's call surface (T:1374-1396)
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, sample, timestep, encoder_hidden_states, is_target=True, return_dict=True, **unused):
+        """MyUNet2DConditionModel.forward under autograd, as the training launcher drives it:
+            pred_ref = unet(z_refcat, t, ehs_nshot, is_target=False).sample     T:1374
+            pred     = unet(z_tag, t, ehs, is_target=True).sample                T:1375
+            loss = F.mse_loss(pred.float() + pred_ref.float() * 0., target)      T:1381-1384
+            loss.backward(); clip_grad_norm_(unet.parameters(), 1.0); optimizer.step(); optimizer.zero_grad()
+        The support call records its inputs and returns a graph-attached ZERO tensor of the right shape (the reference
+        multiplies that output by 0); the query call runs the lock-step forward over [support ; query] and returns
+        `.sample` with a grad_fn whose backward runs the tape with torch's d loss / d pred.  `parameters()[0].grad` is the
+        flat fp32 gradient (a view of P.grad): None after optimizer.zero_grad() => the next step overwrites (first-touch
+        writes), otherwise it accumulates (gradient accumulation, T:1323)."""
+        from .unet import UNet2DConditionOutput
+        for name, v in unused.items():
+            if v is not None:
+                raise NotImplementedError(f"{name} is not on the DiffewS hot path (always None there)")
+        prm = self.parameters()[0]
+        if not is_target:
+            if sample.shape[1] != self.config["in_channels_ref"]:
+                raise ValueError(f"support pass expects {self.config['in_channels_ref']} channels, got {sample.shape[1]}")
+            self._pending_ref = (sample, timestep, encoder_hidden_states)
+            out = _SupportPass.apply(prm, sample.shape[0], self.config["out_channels"], sample.shape[2], sample.shape[3])
+        else:
+            if sample.shape[1] != self.config["in_channels"]:
+                raise ValueError(f"target pass expects {self.config['in_channels']} channels, got {sample.shape[1]}")
+            ref = self._pending_ref
+            self._pending_ref = None
+            out = _QueryPass.apply(prm, self, ref, sample, timestep, encoder_hidden_states)
+        return UNet2DConditionOutput(sample=out) if return_dict else (out,)
 
     # ------------------------------------------------------------------ optimizer (T:1186-1194, T:1217-1223, T:1393-1394)
     def grad_sumsq(self):
         return ob.sumsq(self.P.grad)
 
+    def _resolve_overflow(self):
+        """Dynamic loss scale, GradScaler's rule (accelerate mixed_precision='fp16', T:1017): the previous optimizer step's
+        overflow flag arrives through a pinned host word; on overflow that step was skipped on the device (dfw_adamw), so
+        its step count is taken back and the scale halves; after `growth_interval` clean steps it doubles."""
+        pend = self._overflow_pending
+        if pend is None:
+            return
+        self._overflow_pending = None
+        ev, host = pend
+        ev.synchronize()
+        if int(host[0]) != 0:
+            self.step_count -= 1
+            self.skipped_steps += 1
+            self._good_steps = 0
+            if self.dynamic_loss_scale:
+                self.loss_scale = max(1.0, self.loss_scale * 0.5)
+        else:
+            self._good_steps += 1
+            if self.dynamic_loss_scale and self._good_steps >= self.growth_interval:
+                self.loss_scale = min(65536.0, self.loss_scale * 2.0)
+                self._good_steps = 0
+
     def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0):
-        """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers, then refresh the 16-bit shadow."""
+        """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers; the 16-bit shadow is refreshed in the same pass.
+        A non-finite gradient norm (fp16 overflow) SKIPS the update on the device -- master, moments and shadow are left
+        untouched -- and is reported through `skipped_steps` / the dynamic loss scale one step later (no host sync here)."""
         P = self.P
+        self._resolve_overflow()
         self.step_count += 1
-        ss = ob.sumsq(P.grad) if max_grad_norm and max_grad_norm > 0 else None
+        ss = ob.sumsq(P.grad)
         ob.adamw(P.master, P.grad, P.exp_avg, P.exp_avg_sq, self.step_count, lr, betas, eps, weight_decay, grad_sumsq=ss,
-                 max_grad_norm=max_grad_norm or 0.0, shadow=P.shadow)      # the 16-bit shadow is refreshed in the same pass
+                 max_grad_norm=max_grad_norm or 0.0, shadow=P.shadow, found_inf=self._found_inf)
+        host = self._found_host
+        host.copy_(self._found_inf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._overflow_pending = (ev, host)
         P.version += 1
         return ss
+
+    # ------------------------------------------------------------------ trainer state: resume (T:1281-1309, T:1407-1431)
+    def optimizer_state_dict(self):
+        """Everything `accelerator.save_state` keeps for the UNet besides the weights file: fp32 master, both AdamW
+        moments (flat, packed layout), step count, loss-scale state.  `layout` pins the packed layout it belongs to."""
+        self._resolve_overflow()
+        P = self.P
+        return {"layout": self._layout_id(), "step": self.step_count, "master": P.master.detach().cpu().clone(),
+                "exp_avg": P.exp_avg.detach().cpu().clone(), "exp_avg_sq": P.exp_avg_sq.detach().cpu().clone(),
+                "loss_scale": self.loss_scale, "good_steps": self._good_steps, "skipped_steps": self.skipped_steps}
+
+    def load_optimizer_state_dict(self, sd):
+        P = self.P
+        if sd["layout"] != self._layout_id():
+            raise ValueError("optimizer state belongs to a different parameter layout (model config / engine version)")
+        P.master.copy_(sd["master"])
+        P.exp_avg.copy_(sd["exp_avg"])
+        P.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count, self.loss_scale = int(sd["step"]), float(sd["loss_scale"])
+        self._good_steps, self.skipped_steps = int(sd.get("good_steps", 0)), int(sd.get("skipped_steps", 0))
+        self._overflow_pending = None
+        P.sync_shadow()
+        if self._param is not None:
+            self._master_seen = self._param._version
+
+    def _layout_id(self):
+        import hashlib
+        h = hashlib.sha256()
+        for name, (off, shape) in self.P.spec.items():
+            h.update(f"{name}:{off}:{shape};".encode())
+        return h.hexdigest()[:16]
+
+    def save_state(self, path):
+        """`accelerator.save_state(checkpoint-N)` (T:1407-1431): diffusers-format weights under unet/ (the hook of
+        T:1130-1140) + the optimizer state, so that load_state() resumes the trajectory bit-for-bit."""
+        import os
+        os.makedirs(path, exist_ok=True)
+        self.save_pretrained(path, subfolder="unet")
+        torch.save(self.optimizer_state_dict(), os.path.join(path, "optimizer_dfw.pt"))
+
+    def load_state(self, path):
+        """`accelerator.load_state` (T:1281-1309)."""
+        import os
+        self.load_optimizer_state_dict(torch.load(os.path.join(path, "optimizer_dfw.pt"), map_location="cpu"))
+
+
+class _SupportPass(torch.autograd.Function):
+    """unet(z_refcat, t, ehs, is_target=False).sample: the reference multiplies it by zero (T:1381) -- a graph-attached
+    zero tensor; its backward contributes nothing (the support rows' real gradient flows through the banks inside the
+    query pass' backward)."""
+
+    @staticmethod
+    def forward(ctx, prm, n, oc, h, w):
+        return prm.new_zeros(n, oc, h, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None, None, None
+
+
+class _QueryPass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prm, trainer, ref, sample, timestep, ehs):
+        fresh = prm.grad is None
+        if ref is None:      # no support pass recorded: plain self-attention (0-shot)
+            zr = sample.new_zeros(0, trainer.config["in_channels_ref"], *sample.shape[2:])
+            ehs_ref = None
+        else:
+            zr, _, ehs_ref = ref
+        c = trainer._forward(zr.detach(), sample.detach(), timestep, ehs.detach(), zero_grad=fresh,
+                             ehs_ref=None if ehs_ref is None else ehs_ref.detach())
+        ctx.trainer, ctx.c, ctx.prm = trainer, c, prm
+        return c["pred"]
+
+    @staticmethod
+    def backward(ctx, g):
+        tr, c = ctx.trainer, ctx.c
+        n_ref = c["n_ref"]
+        ob.loss_grad(g.to(torch.float32).contiguous(), tr.dtype, scale=tr.loss_scale, dpred_out=c["dpred"][n_ref:],
+                     dpred_nchw_out=c["dpn"][n_ref:])
+        tr._backward(c, tr.reducer)
+        ctx.prm.grad = tr.P.grad          # the flat fp32 gradient (packed layout), for clip_grad_norm_ / torch.optim
+        ctx.c = None
+        return None, None, None, None, None, None
 
 
 def poly_lr(base_lr, step, total_steps, warmup_steps=0, lr_end=1e-7, power=1.0):
@@ -621,19 +893,129 @@ def poly_lr(base_lr, step, total_steps, warmup_steps=0, lr_end=1e-7, power=1.0):
     return (base_lr - lr_end) * remaining ** power + lr_end
 
 
+def _buckets(n, bucket_elems):
+    return [(s0, min(n, s0 + bucket_elems)) for s0 in range(0, n, bucket_elems)]
+
+
 def allreduce_flat_gradient(flat_grad, world_size=None, bucket_elems=54_000_000, group=None):
-    """Gradient all-reduce of DDP (T:1226-1228, T:1391) on the flat fp32 gradient: SUM over ranks in fixed buckets
-    (216 MB each: eight cover the 866 M parameters), then the 1 / world_size average.  RCCL over xGMI on GPU tensors
-    (backend "nccl"), gloo on CPU tensors.  Bucket boundaries depend only on the buffer length, so every rank issues
-    the same sequence of collectives."""
+    """Gradient all-reduce of DDP (T:1226-1228, T:1391) on the flat fp32 gradient, SERIAL form: SUM over ranks in fixed
+    buckets (216 MB each: sixteen cover the 866 M parameters), then the 1 / world_size average.  RCCL over xGMI on GPU
+    tensors (backend "nccl"), gloo on CPU tensors.  Bucket boundaries depend only on the buffer length, so every rank
+    issues the same sequence of collectives.  GradBucketReducer issues the same buckets DURING the backward."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return flat_grad
     ws = world_size or dist.get_world_size(group)
     if ws == 1:
         return flat_grad
-    n = flat_grad.numel()
-    for s0 in range(0, n, bucket_elems):
-        dist.all_reduce(flat_grad[s0:min(n, s0 + bucket_elems)], op=dist.ReduceOp.SUM, group=group)
-    flat_grad.mul_(1.0 / ws)
+    for s0, s1 in _buckets(flat_grad.numel(), bucket_elems):
+        dist.all_reduce(flat_grad[s0:s1], op=dist.ReduceOp.SUM, group=group)
+        flat_grad[s0:s1].mul_(1.0 / ws)
     return flat_grad
+
+
+class GradBucketReducer:
+    """DDP's overlapped gradient all-reduce (T:1226-1228, T:1391) for the flat gradient buffer.
+
+    The flat layout follows the forward's order of use (UNetTrainer._build), so the backward finishes parameter
+    gradients from the END of the buffer towards its start and the fixed buckets of allreduce_flat_gradient complete one
+    after the other.  mark(names) is called after the launches that wrote those parameters' gradients were issued; when
+    the last writer of a bucket is in the compute stream, an event is recorded there, the COMM stream waits for it and
+    issues the bucket's all-reduce (+ the 1 / world average) -- while the compute stream goes on with the backward of the
+    earlier layers.  finish() issues whatever is left, makes the compute stream wait for the comm stream and returns the
+    rank-averaged loss: the scalar rides in the tail slot of the LAST bucket range (one collective fewer than T:1387's
+    gather).  Same buckets, same reduction operator and the same elementwise average as the serial form => bit-identical
+    results in fp32.  comm_dtype=torch.bfloat16 halves the bytes on xGMI: bucket -> bf16 (dfw_convert_f32), SUM in bf16
+    on the wire, back to fp32 times 1 / world (dfw_convert_to_f32).
+
+    spec: {name: (offset, numel)} of the parameters inside `buf`; buf = P.grad_buf (numel + TAIL floats).
+    collective: injectable for tests -- f(tensor) reduces in place."""
+
+    def __init__(self, buf, spec, bucket_elems=54_000_000, comm_dtype=torch.float32, group=None, world_size=None,
+                 collective=None, loss_slot=None):
+        import torch.distributed as dist
+        self.buf, self.group = buf, group
+        self.comm_dtype = comm_dtype
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.ws = world_size or (dist.get_world_size(group) if self.dist else 1)
+        self.collective = collective
+        self.ranges = _buckets(buf.numel(), bucket_elems)
+        self.loss_slot = buf.numel() - ParamStore.TAIL if loss_slot is None else loss_slot
+        self.of = {}                                  # name -> bucket indices it overlaps
+        self.need = [set() for _ in self.ranges]
+        for name, (off, n) in spec.items():
+            b0, b1 = off // bucket_elems, (off + max(n, 1) - 1) // bucket_elems
+            self.of[name] = list(range(b0, b1 + 1))
+            for b in self.of[name]:
+                self.need[b].add(name)
+        self.cuda = buf.is_cuda
+        self.comm = torch.cuda.Stream(device=buf.device) if self.cuda else None
+        self.fired_order = []
+        self.active = False
+
+    def begin(self, loss=None):
+        self.left = [set(s) for s in self.need]
+        self.fired = [False] * len(self.ranges)
+        self.fired_order = []
+        self.active = True
+        if loss is not None:                          # before any bucket can fire: the loss is known ahead of the backward
+            self.buf[self.loss_slot:self.loss_slot + 1].copy_(loss.reshape(1).to(self.buf.dtype))
+
+    def mark(self, names):
+        if not self.active:
+            return
+        for name in names:
+            for b in self.of.get(name, ()):
+                self.left[b].discard(name)
+                if not self.left[b] and not self.fired[b]:
+                    self._fire(b)
+
+    def _reduce(self, t):
+        if self.collective is not None:
+            self.collective(t)
+        elif self.dist is not None and self.ws > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def _fire(self, b):
+        self.fired[b] = True
+        self.fired_order.append(b)
+        s0, s1 = self.ranges[b]
+        sl = self.buf[s0:s1]
+        if self.ws == 1 and self.collective is None:
+            return
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.buf.device))      # after the bucket's last writer
+            self.comm.wait_event(ev)
+            ctx = torch.cuda.stream(self.comm)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.comm_dtype == torch.float32:
+                self._reduce(sl)
+                sl.mul_(1.0 / self.ws)
+            else:
+                n8 = (sl.numel() + 7) // 8 * 8
+                if self.cuda and sl.numel() == n8 and sl.data_ptr() % 16 == 0:
+                    wire = ops.to_storage(sl, self.comm_dtype)
+                    self._reduce(wire)
+                    ob.to_f32(wire, sl, scale=1.0 / self.ws)
+                else:                                  # CPU tensors (gloo tests) / ragged tail bucket
+                    wire = sl.to(self.comm_dtype)
+                    self._reduce(wire)
+                    sl.copy_(wire.to(torch.float32) * (1.0 / self.ws))
+                if self.cuda:
+                    wire.record_stream(self.comm)
+
+    def finish(self):
+        """Issue the buckets that are still open (parameters nobody wrote this step), then join the streams.
+        Returns the rank-averaged loss tensor [1] (a view of the tail slot)."""
+        if self.active:
+            for b in range(len(self.ranges) - 1, -1, -1):
+                if not self.fired[b]:
+                    self._fire(b)
+            self.active = False
+        if self.cuda:
+            torch.cuda.current_stream(self.buf.device).wait_stream(self.comm)
+        return self.buf[self.loss_slot:self.loss_slot + 1]

@@ -66,8 +66,11 @@ class _Resnet:
         self.temb_slice = None  # (offset, cout) into the fused time-projection output
 
     def __call__(self, x, tproj=None):
+        """x: the residual stream, NHWC storage dtype -- or fp32 (residual_dtype=torch.float32): GroupNorm then reads
+        fp32, conv2 adds the fp32 shortcut and stores fp32; only the branch's MFMA operands are 16-bit."""
         B, H, W, Cin = x.shape
-        h = ops.groupnorm(x, self.g1, self.b1, self.groups, self.eps, silu=True)
+        dt, f32s = self.w1.dtype, x.dtype == torch.float32
+        h = ops.groupnorm(x, self.g1, self.b1, self.groups, self.eps, silu=True, out_dtype=dt)
         rb = None
         if self.has_temb:
             o, c = self.temb_slice
@@ -76,8 +79,8 @@ class _Resnet:
         h = ops.groupnorm(h, self.g2, self.b2, self.groups, self.eps, silu=True)
         sc = x
         if self.ws is not None:
-            sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
-        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups)
+            sc = ops.linear(ops.to_storage(x, dt).view(-1, Cin), self.ws, bias=self.bs, out_f32=f32s).view(B, H, W, self.cout)
+        return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups, out_f32=f32s)
 
 
 class _Transformer:
@@ -143,10 +146,13 @@ class _Transformer:
         B, H, W, C = x.shape
         N = H * W
         heads = self.heads
-        n = ops.groupnorm(x, self.gn_g, self.gn_b, self.groups, 1e-6, silu=False)
-        t = ops.linear(n.view(-1, C), self.w_in, bias=self.b_in)
+        # fp32 residual stream (x fp32): the block's running sum t is fp32 too; LayerNorm reads it in fp32, every
+        # `+ residual` epilogue adds and stores fp32; q/k/v, attention output, GEGLU and the GEMM operands stay 16-bit
+        dt, f32s = self.w_in.dtype, x.dtype == torch.float32
+        n = ops.groupnorm(x, self.gn_g, self.gn_b, self.groups, 1e-6, silu=False, out_dtype=dt)
+        t = ops.linear(n.view(-1, C), self.w_in, bias=self.b_in, out_f32=f32s)
         # --- attn1: KV-fusion self-attention (A:237-271)
-        ln = ops.layernorm(t, *self.ln[0])
+        ln = ops.layernorm(t, *self.ln[0], out_dtype=dt)
         # q leaves the projection multiplied by attn.scale * log2(e) (fp32, before its one rounding): the
         # attention kernel then exponentiates q.k - m directly; k and v (the bank, A:251-267) are untouched
         qkv = ops.linear(ln, self.w_qkv, colscale=(C, ops.FSA_QSCALE)).view(B, N, 3 * C)
@@ -167,14 +173,14 @@ class _Transformer:
             if bank_b % B != 0:
                 raise ValueError(f"bank holds {bank_b} support images, not a multiple of the query batch {B}")
             att = ops.fsa_attention(q, k, v, heads, self.k_bank, self.v_bank, nshot=bank_b // B, q_prescaled=True)
-        t = ops.linear(att.view(-1, C), self.w_o1, bias=self.b_o1, residual=t)
+        t = ops.linear(att.view(-1, C), self.w_o1, bias=self.b_o1, residual=t, out_f32=f32s)
         # --- attn2: cross-attention on the prompt tokens
-        ln = ops.layernorm(t, *self.ln[1])
+        ln = ops.layernorm(t, *self.ln[1], out_dtype=dt)
         if isinstance(ehs2d, tuple) and len(ehs2d) == 3 and ehs2d[2] and self.fold2 is not None:
             G, Ut, Lf = self.fold2                                   # constant prompt: see fold_attn2
             sc = ops.linear(ln, G, out_f32=True)                     # [M, 64] scores (scale folded in)
-            pr = ops.softmax_groups(sc, heads, Lf, x.dtype)          # per-head softmax over the L tokens
-            t = ops.linear(pr, Ut, bias=self.b_o2, residual=t)
+            pr = ops.softmax_groups(sc, heads, Lf, dt)               # per-head softmax over the L tokens
+            t = ops.linear(pr, Ut, bias=self.b_o2, residual=t, out_f32=f32s)
         else:
             q2 = ops.linear(ln, self.w_q2).view(B, N, C)
             # prompt K/V of all 16 layers come from ONE GEMM per forward (MyUNet2DConditionModel._prompt_kv);
@@ -185,12 +191,13 @@ class _Transformer:
             else:
                 kv2 = ops.linear(ehs2d, self.w_kv2).view(B, L_ctx, 2 * C)
             ca = ops.cross_attention(q2, kv2[..., :C], kv2[..., C:], heads)
-            t = ops.linear(ca.view(-1, C), self.w_o2, bias=self.b_o2, residual=t)
+            t = ops.linear(ca.view(-1, C), self.w_o2, bias=self.b_o2, residual=t, out_f32=f32s)
         # --- GEGLU feed-forward
-        ln = ops.layernorm(t, *self.ln[2])
+        ln = ops.layernorm(t, *self.ln[2], out_dtype=dt)
         ff = ops.linear(ln, self.w_ff1, bias=self.b_ff1, geglu=True)
+        # the block's output only feeds proj_out as an MFMA operand: 16-bit storage even with the fp32 stream
         t = ops.linear(ff, self.w_ff2, bias=self.b_ff2, residual=t)
-        return ops.linear(t, self.w_out, bias=self.b_out, residual=x.view(-1, C)).view(B, H, W, C)
+        return ops.linear(t, self.w_out, bias=self.b_out, residual=x.view(-1, C), out_f32=f32s).view(B, H, W, C)
 
 
 class _Conv:
@@ -201,13 +208,26 @@ class _Conv:
 
 
 class MyUNet2DConditionModel:
-    """HIP engine with the reference UNet's interface.  Inference only (round 1)."""
+    """HIP engine with the reference UNet's interface: the inference forward (U:879-1258).  The training step of the same
+    graph (forward with saved activations + hand-written backward) is `diffews_amd.train.UNetTrainer`.
 
-    def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", **kwargs):
+    residual_dtype: storage of the RESIDUAL STREAM -- the tensor that runs through the blocks as x + branch(x)
+    (resnet outputs, transformer residuals, skip tensors, sampler outputs).  None: the storage dtype (fastest).
+    torch.float32: the stream is summed and stored in fp32 (GEMM epilogues add an fp32 residual and write fp32,
+    GroupNorm / LayerNorm read fp32); MFMA operands stay 16-bit, i.e. each branch sees ONE rounding of its normalised
+    input and the stream none.  This is what brings fp16 storage within north_star's 1e-3 of the fp32 reference
+    (DESIGN.md section 4)."""
+
+    def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", residual_dtype=None,
+                 **kwargs):
         cfg = weights.default_unet_config()
         cfg.update(config or {})
         cfg.update(kwargs)
         self.config = _Cfg(cfg)
+        if residual_dtype not in (None, torch_dtype, torch.float32):
+            raise ValueError("residual_dtype must be None (= torch_dtype) or torch.float32")
+        self.residual_dtype = residual_dtype or torch_dtype
+        self._f32s = self.residual_dtype == torch.float32
         if torch_dtype not in (torch.bfloat16, torch.float16):
             raise ValueError(
                 "engine storage dtype must be torch.bfloat16 or torch.float16: the MI355X path keeps activations in 16 bits "
@@ -224,10 +244,11 @@ class MyUNet2DConditionModel:
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, revision=None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+    def from_pretrained(cls, path, subfolder=None, revision=None, torch_dtype=torch.bfloat16, device="cuda",
+                        residual_dtype=None, **kw):
         cfg = weights.load_config(path, subfolder)
         sd = weights.load_state_dict(path, subfolder)
-        return cls(cfg, sd, torch_dtype=torch_dtype, device=device)
+        return cls(cfg, sd, torch_dtype=torch_dtype, device=device, residual_dtype=residual_dtype)
 
     def save_pretrained(self, path, subfolder=None):
         weights.save_pretrained(path, dict(self.config), self._sd_cpu, subfolder)
@@ -320,7 +341,8 @@ class MyUNet2DConditionModel:
             device, dtype = None, device
         if _needs_rebuild(self, device, dtype):
             self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
-                          device=device or self.device)
+                          device=device or self.device,
+                          residual_dtype=torch.float32 if self._f32s else None)
         return self
 
     def eval(self):
@@ -370,11 +392,11 @@ class MyUNet2DConditionModel:
         if is_target:
             if Cin != cfg["in_channels"]:
                 raise ValueError(f"target pass expects {cfg['in_channels']} channels, got {Cin}")
-            x = ops.conv_small(x_in, self.w_in, self.b_in, c0, 9, dt)
+            x = ops.conv_small(x_in, self.w_in, self.b_in, c0, 9, dt, out_f32=self._f32s)
         else:
             if Cin != cfg["in_channels_ref"]:
                 raise ValueError(f"support pass expects {cfg['in_channels_ref']} channels, got {Cin}")
-            x = ops.conv_small(x_in, self.w_in_ref, self.b_in_ref, c0, 9, dt)
+            x = ops.conv_small(x_in, self.w_in_ref, self.b_in_ref, c0, 9, dt, out_f32=self._f32s)
         out = self._trunk(x, tproj, ehs2d, L_ctx, 0, out_scale, kv_all)
         if in_dtype in (torch.float16, torch.bfloat16, torch.float64):
             out = out.to(in_dtype)
@@ -459,9 +481,9 @@ class MyUNet2DConditionModel:
             ehs = torch.cat([ehs_ref.to(device=dev, dtype=dt), ehs_query.to(device=dev, dtype=dt)], dim=0)
             L_ctx = ehs.shape[1]
             ehs2d = ehs.reshape((n_ref + bq) * L_ctx, ehs.shape[2]).contiguous()
-        x = torch.empty(n_ref + bq, zq.shape[2], zq.shape[3], c0, dtype=dt, device=dev)
-        ops.conv_small(zr, self.w_in_ref, self.b_in_ref, c0, 9, dt, out=x[:n_ref])   # conv_in_ref (U:1119)
-        ops.conv_small(zq, self.w_in, self.b_in, c0, 9, dt, out=x[n_ref:])           # conv_in     (U:1121)
+        x = torch.empty(n_ref + bq, zq.shape[2], zq.shape[3], c0, dtype=self.residual_dtype, device=dev)
+        ops.conv_small(zr, self.w_in_ref, self.b_in_ref, c0, 9, dt, out=x[:n_ref], out_f32=self._f32s)   # conv_in_ref (U:1119)
+        ops.conv_small(zq, self.w_in, self.b_in, c0, 9, dt, out=x[n_ref:], out_f32=self._f32s)           # conv_in     (U:1121)
         out = self._trunk(x, tproj, ehs2d, L_ctx, n_ref, out_scale, kv_all)
         return out[n_ref:]
 
@@ -479,7 +501,7 @@ class MyUNet2DConditionModel:
                 skips.append(x)
             if blk["down"] is not None:
                 d = blk["down"]
-                x = ops.conv3x3(x, d.w, d.cout, bias=d.b, stride=2, pad=1)
+                x = ops.conv3x3(ops.to_storage(x, self.dtype), d.w, d.cout, bias=d.b, stride=2, pad=1, out_f32=self._f32s)
                 skips.append(x)
         # ---- 4. mid (U:1189-1198)
         x = self.mid["res"][0](x, tproj)
@@ -494,9 +516,9 @@ class MyUNet2DConditionModel:
                     x = blk["attn"][j](x, ehs2d, L_ctx, n_ref)
             if blk["up"] is not None:
                 u = blk["up"]
-                x = ops.conv3x3(x, u.w, u.cout, bias=u.b, ups=True)
+                x = ops.conv3x3(ops.to_storage(x, self.dtype), u.w, u.cout, bias=u.b, ups=True, out_f32=self._f32s)
         # ---- 6. out (U:1246-1249); out_scale lets the pipeline fold z0 = -v into the epilogue
-        x = ops.groupnorm(x, *self.gn_out, self.groups, self.eps, silu=True)
+        x = ops.groupnorm(x, *self.gn_out, self.groups, self.eps, silu=True, out_dtype=self.dtype)
         co = self.conv_out
         return ops.conv3x3(x, co.w, co.cout, bias=co.b, out_nchw_f32=True, out_scale=out_scale)
 

@@ -29,15 +29,17 @@ class _VaeResnet:
             self.bs = g("conv_shortcut.bias").float().to(dev)
 
     def __call__(self, x):
+        """x: the residual stream (storage dtype, or fp32 with residual_dtype=torch.float32: see unet._Resnet)."""
         B, H, W, Cin = x.shape
+        dt, f32s = self.w1.dtype, x.dtype == torch.float32
         # norm1/norm2 + SiLU ride inside the convs (normalised in LDS) where the shape allows it
         h = ops.conv3x3(x, self.w1, self.cout, bias=self.cb1, gn_groups=self.groups,
                         gn_in=(self.g1, self.b1, self.groups, 1e-6, True))
         sc = x
         if self.ws is not None:
-            sc = ops.linear(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
+            sc = ops.linear(ops.to_storage(x, dt).view(-1, Cin), self.ws, bias=self.bs, out_f32=f32s).view(B, H, W, self.cout)
         return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups,
-                           gn_in=(self.g2, self.b2, self.groups, 1e-6, True))
+                           gn_in=(self.g2, self.b2, self.groups, 1e-6, True), out_f32=f32s)
 
 
 class _VaeAttention:
@@ -56,14 +58,15 @@ class _VaeAttention:
     def __call__(self, x):
         B, H, W, C = x.shape
         N = H * W
-        n = ops.groupnorm(x, *self.gn, self.groups, 1e-6, silu=False).view(-1, C)
+        dt, f32s = self.wq.dtype, x.dtype == torch.float32
+        n = ops.groupnorm(x, *self.gn, self.groups, 1e-6, silu=False, out_dtype=dt).view(-1, C)
         q = ops.linear(n, self.wq, bias=self.bq).view(B, N, C)
         k = ops.linear(n, self.wk, bias=self.bk).view(B, N, C)
         v = ops.linear(n, self.wv, bias=self.bv).view(B, N, C)
         s = ops.bmm_nt(q, k, out_f32=True)                       # [B, N, N] fp32 scores
-        p = ops.softmax_rows(s, x.dtype, scale=C ** -0.5)        # upcast softmax, storage-dtype probs
+        p = ops.softmax_rows(s, dt, scale=C ** -0.5)             # upcast softmax, storage-dtype probs
         o = ops.bmm_nt(p, ops.transpose(v))                      # [B, N, C]
-        return ops.linear(o.view(-1, C), self.wo, bias=self.bo, residual=x.view(-1, C)).view(B, H, W, C)
+        return ops.linear(o.view(-1, C), self.wo, bias=self.bo, residual=x.view(-1, C), out_f32=f32s).view(B, H, W, C)
 
 
 class _Mid:
@@ -79,7 +82,7 @@ class _Mid:
 class _Encoder:
     def __init__(self, vae, sd):
         cfg, dev, dt, g = vae.config, vae.device, vae.dtype, vae.config["norm_num_groups"]
-        self.dt, self.groups = dt, g
+        self.dt, self.groups, self.f32s = dt, g, vae.residual_dtype == torch.float32
         boc, lpb = list(cfg["block_out_channels"]), cfg["layers_per_block"]
         self.c0 = boc[0]
         self.w_in = packing.pack_conv_small(sd["encoder.conv_in.weight"]).to(dev)
@@ -102,14 +105,15 @@ class _Encoder:
             x = [t.to(dtype=torch.float32).contiguous() for t in x]
         else:
             x = x.to(dtype=torch.float32).contiguous()
-        h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups)
+        h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups, out_f32=self.f32s)
         for res, down in self.blocks:
             for r in res:
                 h = r(h)
             if down is not None:  # F.pad(0,1,0,1) + conv stride 2 padding 0
-                h = ops.conv3x3(h, down.w, down.cout, bias=down.b, stride=2, pad=0, gn_groups=self.groups)
+                h = ops.conv3x3(ops.to_storage(h, self.dt), down.w, down.cout, bias=down.b, stride=2, pad=0,
+                                gn_groups=self.groups, out_f32=self.f32s)
         h = self.mid(h)
-        h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
+        h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True, out_dtype=self.dt)
         co = self.conv_out
         return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True)  # [n, 2*lc, h, w] fp32
 
@@ -117,7 +121,7 @@ class _Encoder:
 class _Decoder:
     def __init__(self, vae, sd):
         cfg, dev, dt, g = vae.config, vae.device, vae.dtype, vae.config["norm_num_groups"]
-        self.dt, self.groups = dt, g
+        self.dt, self.groups, self.f32s = dt, g, vae.residual_dtype == torch.float32
         boc, lpb = list(cfg["block_out_channels"]), cfg["layers_per_block"]
         rboc = boc[::-1]
         self.c0 = rboc[0]
@@ -137,14 +141,15 @@ class _Decoder:
     def __call__(self, z, clamp=False):
         """clamp: clip the image to [-1, 1] in the last conv's epilogue (decode_seg, P:903)."""
         z = z.to(dtype=torch.float32).contiguous()
-        h = ops.conv_small(z, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups)
+        h = ops.conv_small(z, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups, out_f32=self.f32s)
         h = self.mid(h)
         for res, up in self.blocks:
             for r in res:
                 h = r(h)
             if up is not None:
-                h = ops.conv3x3(h, up.w, up.cout, bias=up.b, ups=True, gn_groups=self.groups)
-        h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True)
+                h = ops.conv3x3(ops.to_storage(h, self.dt), up.w, up.cout, bias=up.b, ups=True, gn_groups=self.groups,
+                                out_f32=self.f32s)
+        h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True, out_dtype=self.dt)
         co = self.conv_out
         return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True,
                            act=L.ACT_CLAMP1 if clamp else L.ACT_NONE)  # [b, 3, H, W] fp32
@@ -191,11 +196,18 @@ class _EncOut:
 
 
 class AutoencoderKL:
-    def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", **kwargs):
+    """residual_dtype: None (= torch_dtype) or torch.float32 -- storage of the residual stream, see
+    MyUNet2DConditionModel.  The encoder carries 1.3 of the 1.45e-3 fp16 error of the 16-bit stream."""
+
+    def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", residual_dtype=None,
+                 **kwargs):
         cfg = weights.default_vae_config()
         cfg.update(config or {})
         cfg.update(kwargs)
         self.config = _Cfg(cfg)
+        if residual_dtype not in (None, torch_dtype, torch.float32):
+            raise ValueError("residual_dtype must be None (= torch_dtype) or torch.float32")
+        self.residual_dtype = residual_dtype or torch_dtype
         if torch_dtype not in (torch.bfloat16, torch.float16):
             raise ValueError(
                 "engine storage dtype must be torch.bfloat16 or torch.float16: the MI355X path keeps activations in 16 bits "
@@ -218,9 +230,9 @@ class AutoencoderKL:
         self.post_quant_conv = _Conv1x1Boundary(sd, "post_quant_conv.", self.device, self.dtype)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=torch.bfloat16, device="cuda", residual_dtype=None, **kw):
         return cls(weights.load_config(path, subfolder), weights.load_state_dict(path, subfolder),
-                   torch_dtype=torch_dtype, device=device)
+                   torch_dtype=torch_dtype, device=device, residual_dtype=residual_dtype)
 
     def save_pretrained(self, path, subfolder=None):
         weights.save_pretrained(path, dict(self.config), self._sd_cpu, subfolder)
@@ -230,7 +242,8 @@ class AutoencoderKL:
             device, dtype = None, device
         if _needs_rebuild(self, device, dtype):
             self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
-                          device=device or self.device)
+                          device=device or self.device,
+                          residual_dtype=torch.float32 if self.residual_dtype == torch.float32 else None)
         return self
 
     def eval(self):

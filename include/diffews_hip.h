@@ -41,6 +41,13 @@ enum {
 int dfw_version(void);
 const char* dfw_error_string(int code);
 
+/* HOST function: number of memset nodes in a captured hipGraph_t (child graphs included), or a negative DFW_E* code;
+ * *n_nodes (optional) receives the node count.  The pipeline-owned step graph (pipeline.run_episodes(captured=True))
+ * must contain none: on ROCm 7.2 a small memset node replayed next to plain launches on the same stream was observed to
+ * receive the next launch's kernel arguments, so the library zeroes scratch with kernels and the host asserts that no
+ * torch.zeros / fill_ slipped into the captured step. */
+int dfw_graph_memset_nodes(void* hip_graph, int32_t* n_nodes);
+
 /*
  * Implicit-GEMM on MFMA:  C[m][n] = epi( sum_k A(m,k) * W[n][k] ).
  *   taps == 1: A is [M][lda] (a Linear layer / 1x1 conv on NHWC tokens):
@@ -90,6 +97,11 @@ typedef struct {
    * (A:237-245) uses it to hand the attention kernel q * (scale * log2 e): the softmax then needs no
    * multiply per score (dfw_fsa_args.q_prescaled). */
   float colscale; int32_t colscale_n;
+  /* != 0: `residual` is fp32 [M][ldr floats] instead of the storage dtype.  With out_mode DFW_OUT_F32 this is
+   * the fp32 residual stream (residual_dtype=torch.float32 of the Python engines): x + branch(x) of
+   * ResnetBlock2D / BasicTransformerBlock / Transformer2DModel is summed and stored in fp32, so the stream
+   * is never rounded to 16 bits; only MFMA operands are.  Needs N % 4 == 0 and ldr % 4 == 0. */
+  int32_t residual_f32;
 } dfw_gemm_args;
 
 int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);
@@ -175,6 +187,8 @@ typedef struct {
    * coef_out[B][C][2] = (rstd*gamma, beta - mean*rstd*gamma) is written; x is not normalised here
    * (y may be NULL) -- the consumer conv applies it (dfw_gemm_args.gn_in_coef). */
   float* coef_out;
+  /* != 0: x is fp32 [B][HW][ldx floats] (the fp32 residual stream); y stays the storage dtype. */
+  int32_t x_f32;
 } dfw_groupnorm_args;
 
 int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream);
@@ -186,6 +200,7 @@ typedef struct {
   int32_t rows, C, ldx, ldy;
   float eps;
   int32_t dtype;
+  int32_t x_f32;   /* != 0: x is fp32 [rows][ldx floats] (fp32 residual stream); y stays the storage dtype */
 } dfw_layernorm_args;
 
 int dfw_layernorm(const dfw_layernorm_args* a, dfw_stream_t stream);
@@ -194,7 +209,8 @@ int dfw_layernorm(const dfw_layernorm_args* a, dfw_stream_t stream);
  * Direct convolution for tiny channel counts on the pipeline boundary (NCHW fp32 in):
  * conv_in / conv_in_ref (U:1119-1121), VAE encoder.conv_in, decoder.conv_in, quant_conv,
  * post_quant_conv (P:853, P:901).  Cin <= 8.  W is [Cout][taps][Cin] fp32.
- * out_mode DFW_OUT_T: NHWC storage dtype (Cout % 8 == 0); DFW_OUT_NCHW_F32: NCHW fp32.
+ * out_mode DFW_OUT_T: NHWC storage dtype (Cout % 8 == 0); DFW_OUT_F32: NHWC fp32 (Cout % 8 == 0; the fp32
+ * residual stream starts at conv_in); DFW_OUT_NCHW_F32: NCHW fp32.
  * y = (conv(x * in_scale) + bias) * out_scale.
  */
 typedef struct {
@@ -238,6 +254,10 @@ int dfw_transpose(const void* x, void* y, int32_t batch, int32_t R, int32_t C, i
 /* Channel concat of two NHWC tensors (torch.cat([h, skip], dim=1) in the up blocks, U:1226). */
 int dfw_concat_channels(const void* a, const void* b, void* y, int64_t rows, int32_t Ca, int32_t Cb,
                         int32_t dtype, dfw_stream_t stream);
+
+/* y[i] = (storage dtype) x[i], n % 8 == 0, 16-byte aligned: the 16-bit MFMA-operand copy of an fp32 residual-stream
+ * tensor where a conv / Linear consumes the stream itself (conv_shortcut, Downsample2D / Upsample2D convs). */
+int dfw_convert_f32(const float* x, void* y, int64_t n, int32_t dtype, dfw_stream_t stream);
 
 /* Sinusoidal timestep embedding, flip_sin_to_cos, fp32 math (diffusers Timesteps, U:1008);
  * out [B][dim] in storage dtype. */
@@ -394,6 +414,16 @@ int dfw_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t HW, 
 int dfw_mse_loss(const float* pred, const float* target, void* dpred, float* dpred_nchw, float* loss, float* workspace,
                  int32_t B, int32_t C, int32_t HW, float loss_scale, int32_t dtype, dfw_stream_t stream);
 
+/* The UNet's backward seeded by an EXTERNAL loss gradient g = d loss / d pred (NCHW fp32 [B][C][HW], C <= 8), e.g. from
+ * torch autograd of the launcher's own loss expression (T:1381-1391): dpred / dpred_nchw as dfw_mse_loss writes them,
+ * (storage dtype)(g * scale) with scale = the loss scale. */
+int dfw_loss_grad(const float* g, void* dpred, float* dpred_nchw, int32_t B, int32_t C, int32_t HW, float scale,
+                  int32_t dtype, dfw_stream_t stream);
+
+/* y[i] = (float)x[i] * scale, x in the storage dtype, n % 8 == 0, 16-byte aligned (with dfw_convert_f32: the 16-bit wire
+ * format of the gradient all-reduce, T:1226-1228 with grad_comm_dtype=bf16; scale = 1 / world size). */
+int dfw_convert_to_f32(const void* x, float* y, int64_t n, float scale, int32_t dtype, dfw_stream_t stream);
+
 /* KV-fusion attention backward for the lock-step batch (dfw_fsa_args.n_plain form; nshot == 0: plain
  * self-attention).  qkv [batch][n][ld >= 3C]: the fused projection output with q PRE-SCALED
  * (dfw_gemm_args.colscale); out / dout [batch][n][ldo]; lse from the forward; delta [batch][heads][n] is
@@ -461,6 +491,12 @@ typedef struct {
   int32_t step;
   /* Optional: storage-dtype copy of the updated parameters (what the MFMA kernels read), written in the same pass. */
   void* shadow; int32_t shadow_dtype;
+  /* Overflow guard: when grad_sumsq != NULL and *grad_sumsq is inf / NaN (one non-finite gradient), the step is SKIPPED --
+   * param, both moments and the shadow are left untouched.  *found_inf (optional, device int32) is written by every call
+   * that has grad_sumsq: 1 when the step was skipped, else 0.  The
+   * behaviour of torch.cuda.amp.GradScaler.step under accelerate mixed_precision='fp16' (T:1017, T:1239, T:1394); the
+   * host halves its loss scale on the flag (diffews_amd.train.UNetTrainer.optimizer_step). */
+  int32_t* found_inf;
 } dfw_adamw_args;
 
 int dfw_adamw(const dfw_adamw_args* a, dfw_stream_t stream);

@@ -364,3 +364,75 @@ def test_kernel_plans_of_the_baseline_shapes():
     assert fsa_ws(8, 7, 7, 5, 4096) == 4 * per_split            # configs[4] (7-shot): the query image's 8 segments -> 4 splits
     assert fsa_ws(12, 10, 5, 5, 4096) == 2 * 2 * per_split      # configs[2] (5-shot, b = 2): two query images x 2 splits
     assert fsa_ws(8, 7, 7, 20, 256) == 0                         # 16x16 level: rows too short to be worth a second kernel
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _rank_overlapped_reduce(rank, world, port, out_dir):
+    """One rank of the overlapped-vs-serial gradient all-reduce test (gloo, CPU tensors)."""
+    import random
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffews_amd.train import GradBucketReducer, ParamStore, allreduce_flat_gradient
+    g = torch.Generator().manual_seed(100 + rank)
+    spec, off = {}, 0
+    sizes = [64 * random.Random(5 + i).randint(1, 400) for i in range(60)]
+    for i, n in enumerate(sizes):
+        spec[f"p{i}"] = (off, n)
+        off += n
+    numel = off
+    grads = torch.randn(numel, generator=g)
+    loss = torch.tensor([0.25 + rank])
+    res = {}
+    for mode in ("serial", "overlap_fp32", "overlap_bf16"):
+        buf = torch.zeros(numel + ParamStore.TAIL)
+        if mode == "serial":
+            buf[:numel] = grads
+            buf[numel] = loss[0]
+            allreduce_flat_gradient(buf, bucket_elems=50_000)
+            res[mode] = buf.clone()
+            continue
+        red = GradBucketReducer(buf, spec, bucket_elems=50_000,
+                                comm_dtype=torch.float32 if mode == "overlap_fp32" else torch.bfloat16)
+        red.begin(loss)
+        # the "backward": parameters become final from the end of the buffer towards its start, in uneven groups;
+        # the same order on every rank (it is a property of the model, not of the data)
+        names = list(spec)[::-1]
+        rnd = random.Random(7)
+        i = 0
+        while i < len(names):
+            k = rnd.randint(1, 5)
+            for nme in names[i:i + k]:
+                o, n = spec[nme]
+                buf[o:o + n] = grads[o:o + n]
+            red.mark(names[i:i + k])
+            i += k
+        avg = red.finish()
+        res[mode] = buf.clone()
+        res[mode + "_loss"] = avg.clone()
+        res[mode + "_order"] = list(red.fired_order)
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_gradient_reduce_equals_serial(tmp_path):
+    """world_size 2, gloo: GradBucketReducer (buckets issued while the 'backward' still writes the earlier parameters,
+    loss in the tail slot of the last range) == allreduce_flat_gradient (serial, after the backward) BIT FOR BIT in fp32;
+    the bf16 wire format stays within bf16 rounding of it; both ranks hold the same result and fire the same bucket order."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_rank_overlapped_reduce, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["serial"], r1["serial"])
+    assert torch.equal(r0["overlap_fp32"], r0["serial"]) and torch.equal(r1["overlap_fp32"], r0["serial"])
+    assert float(r0["overlap_fp32_loss"]) == pytest.approx((0.25 + 1.25) / 2)
+    assert r0["overlap_fp32_order"] == r1["overlap_fp32_order"] and r0["overlap_fp32_order"][0] == max(r0["overlap_fp32_order"])
+    assert len(r0["overlap_fp32_order"]) >= 8
+    d = (r0["overlap_bf16"][:-64] - r0["serial"][:-64]).norm() / r0["serial"][:-64].norm()
+    assert float(d) < 8e-3 and torch.equal(r0["overlap_bf16"], r1["overlap_bf16"])

@@ -380,3 +380,74 @@ def test_captured_replays_interleaved_with_plain_launches(models):
     assert torch.equal(r["counts"], want)
     assert meter.intersection_buf[:, [0, 4]].t().tolist() == (n * want[:, 0:2]).tolist()
     assert meter.union_buf[:, [0, 4]].t().tolist() == (n * want[:, 2:4]).tolist()
+
+
+def test_capture_survives_a_thread_that_allocates(models):
+    """The evaluation loop captures its step while the EpisodeLoader's producer thread stages the next batches: that
+    thread allocates device slots (hipMalloc through torch's allocator), pinned host buffers (hipHostMalloc) and
+    synchronises copy events.  Under capture_error_mode='global' any of these calls from ANOTHER thread fails with
+    hipErrorStreamCaptureUnsupported or invalidates the capture; the pipeline captures 'thread_local'."""
+    import threading
+    pipe = models["pipe"]
+    pipe._graphs = {}
+    sup, qry, msk = (t.cuda() for t in _episode(2, 1, 64, seed=31))
+    want = pipe.run_episodes(sup, qry, msk, captured=False)["z0"].clone()
+    stop, errors, made = threading.Event(), [], [0]
+
+    def producer():
+        try:
+            st = torch.cuda.Stream()
+            i = 0
+            while not stop.is_set():
+                # cold allocations of ever-changing sizes: the caching allocator cannot serve them from its pools
+                host = torch.empty(1 << 20 + (i % 3), dtype=torch.uint8).pin_memory()
+                with torch.cuda.stream(st):
+                    dev = torch.empty((3 + i % 5) << 20, dtype=torch.uint8, device="cuda")
+                    dev[:host.numel()].copy_(host, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                ev.synchronize()
+                del dev, host
+                if i % 4 == 0:
+                    torch.cuda.empty_cache()
+                i += 1
+                made[0] = i
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    try:
+        while made[0] < 2 and not errors:
+            pass
+        got = pipe.run_episodes(sup, qry, msk, captured=True)["z0"].clone()     # warm-up + capture + first replay
+        again = pipe.run_episodes(sup, qry, msk, captured=True)["z0"].clone()
+    finally:
+        stop.set()
+        th.join(30)
+    assert not errors, errors
+    assert made[0] >= 2
+    assert torch.equal(got, want) and torch.equal(again, want)
+    assert pipe.graph_nodes > 50           # the node walk saw the captured step (and found no memset node)
+
+
+def test_captured_step_rejects_memset_nodes(models):
+    """DESIGN section 2 invariant: a memset node inside the pipeline-owned graph is refused at capture time
+    (regression guard for torch.zeros / zero_ / fill_ slipping into _episodes_step)."""
+    import ctypes as C
+    from diffews_amd import _lib as L
+    from diffews_amd.pipeline import _assert_no_memset_nodes
+    x = torch.empty(1 << 16, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        x.zero_()                   # becomes a memset node
+        y = x + 1
+    n = C.c_int32(0)
+    assert L.lib().dfw_graph_memset_nodes(C.c_void_p(g.raw_cuda_graph()), C.byref(n)) >= 1 and n.value >= 2
+    with pytest.raises(RuntimeError, match="memset"):
+        _assert_no_memset_nodes(g)
+    g2 = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+        y = x + 1
+    assert _assert_no_memset_nodes(g2) >= 1
+    del y

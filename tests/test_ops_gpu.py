@@ -617,3 +617,85 @@ def test_linear_column_scale(ops, dtype):
         y32 = ops.linear(x.cuda(), w.cuda(), out_f32=True).cpu()
         y32[:, :C] *= FSA_QSCALE
         assert torch.equal(y.cpu(), y32.to(dtype)), (M, C)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp32 residual stream (residual_dtype=torch.float32): fp32 residual / fp32 output epilogues, fp32-input norms,
+# fp32 NHWC conv_in, fp32 concat, fp32 -> storage copy.  The stream tensor is never rounded to 16 bits, so the
+# fp32 outputs must match the fp32 reference to accumulation-order precision (2e-5), not to storage rounding.
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 320, 320), (4096, 640, 2560), (8192, 320, 1280), (64, 1280, 5120)])
+def test_linear_fp32_residual_stream(ops, dtype, M, N, K):
+    x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias = torch.randn(N)
+    res = torch.randn(M, N, generator=torch.Generator().manual_seed(3)) * 3   # fp32, NOT representable in 16 bits
+    ref = x.float() @ w.float().t() + bias + res
+    y32 = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out_f32=True)
+    assert y32.dtype == torch.float32 and rel(y32, ref) < 2e-5
+    y16 = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda())     # ff.net.2 -> proj_out operand
+    assert y16.dtype == dtype and rel(y16, ref) < TOL[dtype]
+    # forced split-K: the residual is added by the reduce pass
+    y32s = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out_f32=True, splitk=2)
+    assert rel(y32s, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pad,ups", [(2, 32, 32, 128, 128, 1, 1, False), (1, 64, 64, 256, 256, 1, 1, False),
+                                                           (2, 16, 16, 320, 640, 1, 1, False), (1, 32, 32, 128, 128, 2, 0, False),
+                                                           (1, 16, 16, 64, 64, 1, 1, True), (3, 8, 8, 1280, 1280, 1, 1, False)])
+def test_conv3x3_fp32_residual_stream(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
+    from diffews_amd.packing import pack_conv3x3
+    x = rnd((B, H, W, Cin), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)
+    bias = torch.randn(Cout)
+    xin = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    if stride == 2 and pad == 0:
+        xin = F.pad(xin, (0, 1, 0, 1))
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    res = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5)) * 3
+    wp = pack_conv3x3(w).cuda()
+    y = ops.conv3x3(x.cuda(), wp, Cout, bias=bias.cuda(), stride=stride, pad=pad, ups=ups, residual=res.cuda().contiguous(),
+                    out_f32=True, gn_groups=32)
+    assert y.dtype == torch.float32 and rel(y, ref + res) < 2e-5
+    y0 = ops.conv3x3(x.cuda(), wp, Cout, bias=bias.cuda(), stride=stride, pad=pad, ups=ups, out_f32=True)
+    assert rel(y0, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 64, True), (1, 1000, 320, False), (3, 64, 2560, True), (2, 4096, 128, True)])
+def test_groupnorm_layernorm_fp32_input(ops, dtype, B, HW, C, silu):
+    g0 = torch.Generator().manual_seed(11)
+    x = torch.randn(B, HW, C, generator=g0) * 2 + 0.5       # fp32 stream
+    g, b = torch.randn(C) * 0.2 + 1, torch.randn(C) * 0.2
+    ref = F.group_norm(x.transpose(1, 2), 32, g, b, eps=1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), 32, 1e-5, silu, out_dtype=dtype)
+    assert y.dtype == dtype and rel(y, ref) < TOL[dtype]
+    with pytest.raises(TypeError):
+        ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), 32, 1e-5, silu)
+    x2 = x.reshape(-1, C)[:300].contiguous() * 3 + 1
+    refl = F.layer_norm(x2, (C,), g, b, 1e-5)
+    yl = ops.layernorm(x2.cuda(), g.cuda(), b.cuda(), out_dtype=dtype)
+    assert yl.dtype == dtype and rel(yl, refl) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fp32_stream_glue(ops, dtype):
+    from diffews_amd.packing import pack_conv_small
+    g = torch.Generator().manual_seed(2)
+    # conv_in with an fp32 NHWC output (8w kernel: W % 8 == 0; generic kernels: W = 12, 10)
+    for (B, Cin, H, W, Cout) in ((2, 4, 16, 16, 320), (1, 3, 20, 12, 128), (1, 8, 6, 10, 64)):
+        x = torch.rand(B, Cin, H, W, generator=g) * 2 - 1
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+        bias = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1)
+        y = ops.conv_small(x.cuda(), pack_conv_small(w).cuda(), bias.cuda(), Cout, 9, dtype, out_f32=True, gn_groups=32)
+        assert y.dtype == torch.float32 and rel(y, ref) < 1e-5 and getattr(y, "_gn_stats", None) is None
+    a, b = torch.randn(3, 7, 5, 64, generator=g), torch.randn(3, 7, 5, 128, generator=g)
+    assert torch.equal(ops.concat_channels(a.cuda(), b.cuda()).cpu(), torch.cat([a, b], -1))
+    c = ops.to_storage(a.cuda(), dtype)
+    assert c.dtype == dtype and torch.equal(c.cpu(), a.to(dtype))
+    assert ops.to_storage(c, dtype) is c
