@@ -66,7 +66,7 @@ def cpu_baseline(model_blobs, res, nshot, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("DFW_CPU_THREADS", "16"))))
+    cores = max(1, min(cores, int(os.environ.get("DFW_CPU_THREADS", str(cores)))))   # every core of this job's share
     torch.set_num_threads(cores)
     kw = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
     ou = OracleUNet(**kw(ucfg)); ou.load_state_dict(usd); ou.eval()
@@ -84,12 +84,14 @@ def cpu_baseline(model_blobs, res, nshot, budget_s=20.0):
                 break
         return ts
     t256 = timed(256, 1, 3, 5, 8.0)
-    tb = timed(res, nshot, 1, 3, budget_s)
+    tb = timed(res, nshot, 2, 4, budget_s)
     med = sorted(t256)[len(t256) // 2]
+    # flat keys only: the driver's `parsed` keeps one level of nesting
     return dict(value=len(tb) / sum(tb), unit="episodes/s", cores=cores, kind="port",
                 sample=f"{len(tb)} episode(s) {res}x{res} {nshot}-shot fp32, oracle/ on {cores} host threads, {sum(tb):.1f}s",
-                configs0_256x256_1shot=dict(value=round(1.0 / med, 4), unit="episodes/s", episodes=len(t256),
-                                            median_s=round(med, 3), note="BASELINE.json configs[0]: fp32, 1 denoise step, after 1 warm-up"))
+                configs0_256x256_1shot_value=round(1.0 / med, 4), configs0_256x256_1shot_median_s=round(med, 3),
+                configs0_256x256_1shot_episodes=len(t256),
+                configs0_note="BASELINE.json configs[0]: 256x256, 1-shot, fp32, 1 denoise step, median after 1 warm-up")
 
 
 def roofline_pass(step):
@@ -160,6 +162,110 @@ def latest_pmc_summary():
         return os.path.basename(best[1]), json.load(f)
 
 
+def timed_steps(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_measurements(pipe, blobs, args, res, dtype):
+    """After the headline measurement, on rank 0 of a 1-GPU run: the other BASELINE.json GPU configurations through the
+    same product code, so that the driver's record carries them (flat scalar keys):
+      fp32_stream_*  configs[1] again with residual_dtype=torch.float32 (north_star's 1e-3 parity mode)
+      configs2_*     512x512 5-shot, batch 2 (24 576 keys at the 64x64 level), 5 steps, + its attention roofline
+      configs4_*     the 7-shot training step (VAE-encode with sampling + UNet fwd + bwd + clip + AdamW), 3 steps, + the
+                     roofline of its heaviest kernel pair, the KV-fusion attention backward (dQ + dK/dV)."""
+    from diffews_amd import episodes
+    from diffews_amd.metrics import AverageMeter, fold_class_ids
+    out = {}
+    meter = AverageMeter("coco", fold_class_ids("coco", 0), device="cuda")
+
+    def infer_config(b, s, steps, warmup=2):
+        bt = episodes.make_episode_batch(b, s, res, seed=300 + s, device="cuda")
+        cls = episodes.episode_class_ids(list(range(b))).cuda()
+
+        def step(captured=True):
+            r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"], captured=captured)
+            meter.update_from_counts(r["counts"], cls)
+            return r
+        step(False)
+        ms = timed_steps(step, warmup, steps) * 1e3
+        agg = roofline_pass(lambda: step(False))
+        attn = agg.get("fsa_attention")
+        return ms, attn
+    # -- fp32 residual stream, configs[1] shape
+    try:
+        pipe.set_residual_dtype(torch.float32)
+        ms, _ = infer_config(args.batch, 1, 5)
+        out["fp32_stream_ms_per_step"] = round(ms, 3)
+        out["fp32_stream_value"] = round(args.batch / ms * 1e3, 3)
+        out["fp32_stream_note"] = ("configs[1] with residual_dtype=torch.float32: fp32 residual stream, 16-bit MFMA operands; "
+                                   "z0 within north_star's 1e-3 of the fp32 oracle in fp16 storage (tests/test_fullsize_gpu.py)")
+    finally:
+        pipe.set_residual_dtype(None)
+    # -- configs[2]
+    ms, attn = infer_config(2, 5, 5)
+    out["configs2_ms_per_step"] = round(ms, 3)
+    out["configs2_value"] = round(2 / ms * 1e3, 3)
+    out["configs2_workload"] = f"SD-2.1 UNet + SD VAE, {res}x{res}, 5-shot, 2 episodes/GPU/step (BASELINE.json configs[2]), HIP graph"
+    if attn:
+        out["configs2_attention_tflops"] = round(attn[1] / attn[2] / 1e12, 2)
+        out["configs2_attention_frac"] = round(attn[1] / attn[2] / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        out["configs2_attention_ms_per_step"] = round(attn[2] * 1e3, 3)
+    pipe._graphs = {}
+    torch.cuda.empty_cache()
+    # -- configs[4]: the training step on this one GPU
+    from diffews_amd.train import UNetTrainer, poly_lr
+    ucfg, usd, vcfg, vsd, te = blobs
+    s = 7
+    tr = UNetTrainer(ucfg, usd, torch_dtype=dtype, loss_scale=1.0 if dtype == torch.bfloat16 else 1024.0)
+    vae = pipe.vae
+    bt = episodes.make_episode_batch(1, s, res, seed=200, device="cuda")
+    qmask = (bt["query_mask"].float()[:, None].repeat(1, 3, 1, 1) * 2 - 1).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(1000)
+    ehs = torch.randn(1, 77, ucfg["cross_attention_dim"], generator=torch.Generator().manual_seed(3)).cuda()
+    srcs = [torch.cat([bt["support_imgs"], bt["query_img"]]).contiguous(), bt["support_masks"], qmask]
+    st = {"step": 0, "loss": None}
+
+    def encode():
+        lat = vae.encode(srcs).latent_dist.sample(generator=g) * 0.18215
+        return torch.cat([lat[:s], lat[s + 1:2 * s + 1]], 1), lat[s:s + 1], -lat[2 * s + 1:]
+
+    def train_step():
+        zc, zt, tgt = encode()
+        loss, _ = tr.forward_backward(zc, zt, tgt, 1, ehs)
+        tr.optimizer_step(poly_lr(1e-5, st["step"], 10000), max_grad_norm=1.0)
+        st["step"] += 1
+        st["loss"] = loss
+    ms = timed_steps(train_step, 2, 3) * 1e3
+    loss = float(st["loss"])
+    if not (loss == loss and abs(loss) < 1e6):
+        raise RuntimeError("configs[4]: non-finite loss")
+    agg = roofline_pass(train_step)
+    out["configs4_ms_per_step"] = round(ms, 3)
+    out["configs4_value"] = round(1e3 / ms, 3)
+    out["configs4_workload"] = (f"training step, SD-2.1 UNet 865.9 M + frozen SD VAE, {res}x{res}, 7-shot, 1 episode/GPU/step: 16 sampled "
+                                "VAE encodes + UNet fwd + bwd + clip_grad_norm_ + AdamW (BASELINE.json configs[4], one GPU), eager")
+    out["configs4_loss"] = round(loss, 5)
+    ab, af = agg.get("fsa_attention_bwd"), agg.get("fsa_attention")
+    if ab:
+        out["configs4_attention_bwd_kernels"] = "fsa_bwd_dq_kernel + fsa_bwd_dkv_kernel (+ delta)"
+        out["configs4_attention_bwd_ms_per_step"] = round(ab[2] * 1e3, 3)
+        out["configs4_attention_bwd_tflops"] = round(ab[1] / ab[2] / 1e12, 2)
+        out["configs4_attention_bwd_frac"] = round(ab[1] / ab[2] / 1e12 / MFMA_PEAK_TFLOPS, 4)
+    if af:
+        out["configs4_attention_fwd_ms_per_step"] = round(af[2] * 1e3, 3)
+        out["configs4_attention_fwd_frac"] = round(af[1] / af[2] / 1e12 / MFMA_PEAK_TFLOPS, 4)
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def train_main(args):
     """`--train`: BASELINE configs[4] (train_icl_multitask_nocrop_nearest_nshot_v3.py:1320-1396).  One step per rank =
     VAE-encode with sampling of the episode's 2s+2 images (T:1347-1358, frozen VAE), lock-step UNet forward over
@@ -190,7 +296,7 @@ def train_main(args):
         dist.barrier()
         log(f"[bench] rank {rank}/{dist.get_world_size()} on cuda:{dev_index}, backend {dist.get_backend()}")
     from diffews_amd import config, episodes, weights
-    from diffews_amd.train import UNetTrainer, allreduce_flat_gradient, poly_lr
+    from diffews_amd.train import UNetTrainer, poly_lr
     from diffews_amd.vae import AutoencoderKL
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     s = 7 if args.nshot is None else args.nshot       # configs[4] is 7-shot; an explicit --nshot is always honoured
@@ -220,9 +326,15 @@ def train_main(args):
         z_ref, z_tag, z_mref, z_mtag = lat[:s], lat[s:s + 1], lat[s + 1:2 * s + 1], lat[2 * s + 1:]
         return torch.cat([z_ref, z_mref], 1), z_tag, -z_mtag                        # T:1360-1366
 
+    # DDP's gradient all-reduce (T:1226-1228, T:1391), overlapped: the flat gradient's buckets are reduced from a side
+    # stream while the backward of the earlier layers still runs; the loss rides in the last range (T:1387)
+    comm_dt = torch.bfloat16 if args.grad_comm_dtype == "bf16" else torch.float32
+    red = tr.make_reducer(comm_dtype=comm_dt) if world > 1 else None
+
     def train(lat):
-        loss, _ = tr.forward_backward(lat[0], lat[1], lat[2], 1, ehs)               # T:1367-1384
-        allreduce_flat_gradient(tr.P.grad)                                          # T:1391 (DDP)
+        loss, _ = tr.forward_backward(lat[0], lat[1], lat[2], 1, ehs, reducer=red)  # T:1367-1391
+        if red is not None:
+            loss = red.finish()                                                     # rank-averaged loss, streams joined
         tr.optimizer_step(poly_lr(1e-5, state["step"], 10000), max_grad_norm=1.0)  # T:1393-1395
         state["step"] += 1
         state["loss"] = loss
@@ -267,6 +379,21 @@ def train_main(args):
     log(f"[bench] rank {rank}: {elapsed / args.steps * 1e3:.2f} ms/step, loss {loss:.5f}")
     if not (loss == loss and abs(loss) < 1e6):
         raise SystemExit("non-finite loss: invalid run")
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # heaviest kernel pair of the step: the KV-fusion attention backward (dQ + dK/dV), live event timing on the launch
+        # stream in one instrumented step; algorithmic FLOPs = 10 * 64 * heads * n_q * keys per image (5 GEMMs)
+        saved = red
+        red = None
+        agg = roofline_pass(lambda: train(lat))
+        red = saved
+        ab, af = agg.get("fsa_attention_bwd"), agg.get("fsa_attention")
+        if ab:
+            roof = dict(bound="mfma", kernel="fsa_bwd_dq_kernel + fsa_bwd_dkv_kernel", achieved=round(ab[1] / ab[2] / 1e12, 2),
+                        peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ab[1] / ab[2] / 1e12 / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches_per_step=ab[0], ms_per_step=round(ab[2] * 1e3, 3),
+                        attention_fwd_frac=None if not af else round(af[1] / af[2] / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                        attention_fwd_ms_per_step=None if not af else round(af[2] * 1e3, 3))
     if rank == 0:
         line = {"metric": f"training episodes/sec ({res}x{res}, {s}-shot, SD-2 UNet fwd+bwd+AdamW)",
                 "value": round(world * args.steps / elapsed, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
@@ -274,10 +401,12 @@ def train_main(args):
                 "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"training step, SD-2.1 UNet 865.9 M + frozen SD VAE, {res}x{res}, {s}-shot, 1 episode/GPU/step "
                                        f"(BASELINE.json configs[4]){' TINY-DEBUG' if args.tiny else ''}",
-                           "nshot": s, "resolution": res, "parallelism": f"data-parallel x{world}, flat fp32 gradient all-reduce in 216 MB buckets",
+                           "nshot": s, "resolution": res,
+                           "parallelism": f"data-parallel x{world}, flat gradient all-reduce in 216 MB buckets ({args.grad_comm_dtype} on the wire) "
+                                          "issued from a side stream during the backward, loss in the last bucket",
                            "optimizer": "clip_grad_norm_(1.0) + AdamW, fp32 master", "hip_graph": False,
                            "vae_encode": "one batch of 2s+2 images per step" + (", next batch's encodes on a side stream during the UNet step" if prefetch else "")},
-                "roofline": None, "cpu_baseline": None}
+                "roofline": roof, "cpu_baseline": None}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -298,6 +427,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the fp32-stream / configs[2] / configs[4] measurements that follow the headline one (N=1 only)")
+    ap.add_argument("--residual-dtype", default="storage", choices=["storage", "fp32"],
+                    help="residual stream of the UNet / VAE: the storage dtype (default, fastest) or fp32 (parity mode)")
+    ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="--train, N > 1: wire format of the gradient all-reduce (fp32 = DDP's; bf16 halves the xGMI bytes)")
     ap.add_argument("--prefetch", action="store_true", help="--train: encode the next batch on a side stream beside the step")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[4] instead of the headline metric: training step (VAE-encode with sampling, UNet "
@@ -339,6 +474,8 @@ def main():
     from diffews_amd.metrics import AverageMeter, fold_class_ids
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, blobs = build_pipeline(dtype, tiny=args.tiny)
+    if args.residual_dtype == "fp32":
+        pipe.set_residual_dtype(torch.float32)
 
     b, s, res = args.batch, (1 if args.nshot is None else args.nshot), args.res
     bt = episodes.make_episode_batch(b, s, res, seed=100 + rank, device="cuda")
@@ -456,6 +593,17 @@ def main():
         except Exception as e:  # the baseline is reported, never required for `value`
             log(f"[bench] cpu_baseline failed: {e!r}")
 
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and not args.tiny and (res, s, b) == (512, 1, 4) \
+            and args.residual_dtype == "storage":
+        try:
+            secondary = secondary_measurements(pipe, blobs, args, res, dtype)
+            for k, v in secondary.items():
+                log(f"[secondary] {k}: {v}")
+        except Exception as e:   # reported beside the headline value, never required for it
+            log(f"[bench] secondary measurements failed: {e!r}")
+            secondary = {"error": repr(e)}
+
     if rank == 0:
         n_gpus = world
         eps = n_gpus * b * args.steps / elapsed
@@ -469,9 +617,10 @@ def main():
                                    f"{' TINY-DEBUG' if args.tiny else ''}",
                        "episodes_per_gpu_per_step": b, "nshot": s, "resolution": res,
                        "parallelism": f"episode-sharded x{n_gpus}", "hip_graph": use_graph,
+                       "residual_dtype": "fp32" if args.residual_dtype == "fp32" else args.dtype,
                        "graph_owner": "pipeline.run_episodes(captured=True)" if use_graph else None,
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -126,8 +126,16 @@ class AdamWArgs(C.Structure):
                 ("step", _i32), ("shadow", _vp), ("shadow_dtype", _i32), ("found_inf", _vp)]
 
 
+class Config(C.Structure):
+    _fields_ = [("conv_patch", _i32), ("big_kernels", _i32), ("big_bm", _i32), ("big_bn", _i32), ("big_bk", _i32),
+                ("gemm_bm", _i32), ("gemm_bn", _i32), ("fsa_pipelined", _i32), ("fsa_key_split", _i32),
+                ("fsa_force_splits", _i32)]
+
+
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
+    "dfw_configure": (_i32, [C.POINTER(Config)]),
+    "dfw_get_config": (None, [C.POINTER(Config)]),
     "dfw_version": (_i32, []),
     "dfw_error_string": (C.c_char_p, [_i32]),
     "dfw_graph_memset_nodes": (_i32, [_vp, C.POINTER(_i32)]),
@@ -205,6 +213,23 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def configure(**fields):
+    """Change fields of the library's process-wide tuning record (dfw_config): sweeps and A/B runs only -- the defaults
+    are the measured-best plans.  configure() with no arguments restores the defaults.  Returns the record in effect."""
+    h = lib()
+    if not fields:
+        check(h.dfw_configure(None), "dfw_configure")
+    cfg = Config()
+    h.dfw_get_config(C.byref(cfg))
+    for k, v in fields.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(f"dfw_config has no field {k!r}")
+        setattr(cfg, k, int(v))
+    if fields:
+        check(h.dfw_configure(C.byref(cfg)), "dfw_configure")
+    return {k: getattr(cfg, k) for k, _ in Config._fields_}
 
 
 def check(rc, what):

@@ -644,15 +644,13 @@ extern "C" int dfw_silu(const void* a, const void* dy, void* y, int64_t n, int32
 
 // Same rule as the forward's fsa_split_count (attention.hip), for the dQ grid: 128-row workgroups, up to 3 per CU.
 static int fsa_bwd_split_count(const dfw_fsa_bwd_args* a) {
-  static const char* off = getenv("DFW_FSA_NOSPLIT");
-  if (off || a->nshot < 2) return 1;
+  if (!cfg().fsa_key_split || a->nshot < 2) return 1;
   const int nq_img = a->batch - a->n_plain, nseg = 1 + a->nshot;
   if (nq_img <= 0 || (long long)a->n * nseg < 8192) return 1;
   const long long wg_per_img = (long long)a->heads * ((a->n + 127) / 128);
   const double total = (double)wg_per_img * ((double)a->n_plain + (double)nq_img * nseg);
   const double fair = total / 768.0 > 1.0 ? total / 768.0 : 1.0;
-  static const char* force = getenv("DFW_FSA_SPLITS");           // experiments: force the split count of eligible launches
-  if (force) { const int f = atoi(force); return f < 1 ? 1 : (f > nseg ? nseg : f); }
+  if (cfg().fsa_force_splits) { const int f = cfg().fsa_force_splits; return f > nseg ? nseg : f; }   // sweeps
   if ((double)nseg <= 1.5 * fair) return 1;
   for (int ns = 2; ns <= nseg; ++ns)
     if ((double)((nseg + ns - 1) / ns) <= 1.25 * fair) return ns;

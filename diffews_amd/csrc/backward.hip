@@ -1016,9 +1016,8 @@ static int tn_plan(const dfw_gemm_tn_args* a, TnPlan& pl) {
   const int b1 = a->batch > 1 ? a->batch : 1, b2 = a->batch2 > 1 ? a->batch2 : 1;
   pl.Z = b1 * b2 * a->taps;
   pl.conv = a->taps == 9;
-  static const char* ring_env = getenv("DFW_TN_RING");          // 0: register-staged 128 x 128 kernel only; 1: ring, 128 x 128 only
-  pl.ring = (!ring_env || ring_env[0] != '0') && (!pl.conv || (a->Wo >= 8 && a->Ho * a->Wo >= 32));
-  const bool big = pl.ring && !(ring_env && ring_env[0] == '1');
+  pl.ring = !pl.conv || (a->Wo >= 8 && a->Ho * a->Wo >= 32);    // else: the register-staged 128 x 128 kernel (tiny maps)
+  const bool big = pl.ring;
   pl.nsa = big ? tn_tile_dim(a->N) : 1;
   pl.nsb = big ? tn_tile_dim(a->Kc) : 1;
   const long long tiles = (long long)((a->N + pl.nsa * 128 - 1) / (pl.nsa * 128)) * ((a->Kc + pl.nsb * 128 - 1) / (pl.nsb * 128)) * pl.Z;
@@ -1040,12 +1039,6 @@ static int tn_plan(const dfw_gemm_tn_args* a, TnPlan& pl) {
     const double slab = real > 1 ? 2.0 * real * pl.Z * (double)a->N * a->Kc * 4.0 / slab_bw + 4.0 : 0.0;
     const double tt = rounds * (spp * t_step + t_fixed) + slab;
     if (tt < best) { best = tt; best_s = sp; }
-  }
-  static const char* sscale = getenv("DFW_TN_SPLIT_SCALE");     // experiments: scale the chosen split count
-  if (sscale) {
-    best_s = (int)(best_s * atof(sscale) + 0.5);
-    if (best_s < 1) best_s = 1;
-    if (best_s > smax) best_s = smax;
   }
   int spp = (steps + best_s - 1) / best_s;
   if (!pl.ring) spp = (spp + 1) & ~1;                            // the register-staged kernel walks 64-row steps

@@ -7,6 +7,8 @@
 
 namespace dfw {
 
+const dfw_config& cfg();   // the record of dfw_configure() (misc.hip)
+
 using f32x16 = float __attribute__((ext_vector_type(16)));
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using i32x4 = int __attribute__((ext_vector_type(4)));

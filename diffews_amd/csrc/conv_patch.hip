@@ -448,18 +448,18 @@ static int launch_patch(const GemmP& p, hipStream_t st, int gn_chunks) {
 // Shapes: stride-1 / pad-1 conv3x3 with whole (BM/16) x 16 pixel tiles, N a multiple of the tile width, storage-dtype
 // NHWC output, enough tiles to occupy the chip.  N % 256 == 0 -> 256 x 256, else N % 128 == 0 -> 512 x 128.
 bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
-  static const char* on = getenv("DFW_CONV_PATCH");
-  if (on && on[0] == '0') return false;
+  const int mode = cfg().conv_patch;
+  if (mode == 0) return false;
   if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.ups || p.splitk > 1 || p.batch > 1) return false;
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % 16) != 0 || (p.Cin % 64) != 0) return false;
   if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || p.res_f32) return false;
   if (p.rows_per_img != p.Ho * p.Wo || (p.gn_coef && p.Cin > 1024)) return false;
-  // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  DFW_CONV_PATCH=1 also routes the
+  // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  dfw_config.conv_patch = 2 also routes the
   // N % 256 == 0 layers to the 256 x 256 tile: 3 % behind gemm_big with the conflicting LDS swizzle of the first version,
   // 1.5..2 % ahead per kernel with the conflict-free one (1008 / 1222 / 1034 vs 988 / 1198 / 1007 TFLOP/s, same box) and
   // neutral on the whole step (41.96 / 41.90 vs 41.96 / 41.85 ms), so the measured configuration stays the default.
   // A conv that normalises its input (gn_coef) takes either tile.  0 disables the kernel.
-  const bool only128 = (!on || on[0] != '1') && !p.gn_coef;
+  const bool only128 = mode != 2 && !p.gn_coef;
   if ((p.N % 256) == 0 && !only128) { bm = 256; bn = 256; }
   else if ((p.N % 128) == 0 && (p.N % 256) != 0) { bm = 512; bn = 128; }
   else return false;

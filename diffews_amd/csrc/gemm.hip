@@ -373,7 +373,7 @@ static const TileCost kTiles[3] = {{128, 128, 1.67f, 0.70f, 0.f}, {128, 64, 2.8f
 static const TileCost kLinTiles[3] = {{128, 128, 5.29f, 0.312f, 1.94f}, {128, 64, 8.52f, 0.182f, 0.13f}, {64, 64, 12.9f, 0.145f, 0.f}};
 
 static void plan_gemm(GemmP& p, int& bm, int& bn) {
-  static const char* force = getenv("DFW_GEMM_TILE");  // experiments only: "128x128", "128x64", "64x64"
+  const int fbm = cfg().gemm_bm, fbn = cfg().gemm_bn;    // sweeps only: a forced tile instead of the cost model
   const bool fixed_sk = p.splitk >= 1;
   if (p.geglu) { bm = 128; bn = 128; p.splitk = 1; return; }
   const bool can_split = p.batch <= 1 && (p.N % 4) == 0;
@@ -381,10 +381,7 @@ static void plan_gemm(GemmP& p, int& bm, int& bn) {
   int best_t = 0, best_sk = 1;
   for (int t = 0; t < 3; ++t) {
     const TileCost& tc = kTiles[t];
-    if (force) {
-      int fm, fn;
-      if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm != tc.bm || fn != tc.bn)) continue;
-    }
+    if (fbm && (fbm != tc.bm || fbn != tc.bn)) continue;
     const double tiles = (double)((p.M + tc.bm - 1) / tc.bm) * ((p.N + tc.bn - 1) / tc.bn) * (p.batch > 1 ? p.batch : 1);
     for (int sk = 1; sk <= 16; sk *= 2) {
       if (!fixed_sk && sk > 1 && (!can_split || p.nk / sk < 8)) continue;
@@ -485,8 +482,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.dtype_bf16 = a->dtype == DFW_BF16;
   p.gn_partial = a->gn_partial; p.gn_groups = a->gn_groups; p.gn_chunks = 0;
   p.gn_coef = a->gn_in_coef; p.gn_silu = a->gn_in_silu;
-  static const char* tapmajor = getenv("DFW_BIG_TAPMAJOR");   // A/B: tap-major K walk of the conv kernels
-  p.conv_chunk_major = (a->taps == 9 && !tapmajor) ? 1 : 0;
+  p.conv_chunk_major = a->taps == 9 ? 1 : 0;   // channel-chunk-major K walk (the tap-major one measured 4.5-6 % slower)
   if (p.splitk > p.nk) p.splitk = p.nk;
   plan_gemm(p, p.plan_bm, p.plan_bn);
   return 0;
@@ -507,8 +503,8 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
     }
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
-    snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d%s,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,
-             big_bk % 1000, big_bk > 1000 ? "x2" : "", a->taps == 9 ? "conv" : "lin");
+    snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,
+             big_bk, a->taps == 9 ? "conv" : "lin");
     return 0;
   }
   snprintf(buf, n, "gemm_kernel<%s,%d,%d,%s>%s", a->dtype == DFW_BF16 ? "bf16" : "f16", p.plan_bm, p.plan_bn,

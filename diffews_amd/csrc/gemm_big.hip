@@ -557,91 +557,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
     }
     return;
   }
-  if constexpr (PP) {
-    static_assert(OCC == 1 && BK == 32, "ping-pong schedule: one workgroup per CU, two k-slices per stage");
-    typename Tr<T>::v8 fa[2][MB], fw[2][NB];
-    auto reads = [&](int slot) {
-      const char* buf = smem + slot * STAGE;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i) fa[s2][i] = as_v8<T>(*(const i32x4*)(buf + (lds_ra[i] ^ (s2 << 5))));
-#pragma unroll
-        for (int j = 0; j < NB; ++j) fw[s2][j] = as_v8<T>(*(const i32x4*)(buf + (lds_rw[j] ^ (s2 << 5))));
-      }
-    };
-    auto mfmas = [&]() {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) acc[i][j] = Tr<T>::mfma(fw[s2][j], fa[s2][i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    auto bar = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // two fully separate instruction streams for the K loop of a tile (no per-step branches on the
-    // wave group); the epilogue stays common code so that it is inlined once and the accumulators
-    // stay in registers
-    bool has_next = false;
-    int ti_next = 0;
-    auto kloop = [&](auto G1) __attribute__((always_inline)) {
-      constexpr bool g1 = decltype(G1)::value;
-      for (int k = 0; k < nks - (S - 1); ++k) {
-        if constexpr (!g1) reads(rs);
-        bar();
-        issue(k + S - 1, ws);
-        ws = nxt(ws);
-        if constexpr (g1) reads(rs);
-        else mfmas();
-        wait_vm<(S - 2) * DPS>();
-        bar();
-        if constexpr (g1) mfmas();
-        rs = nxt(rs);
-      }
-      if (has_next) setup_loader(tile_coords(tile0 + (ti_next) * nxb));
-#pragma unroll
-      for (int j = 0; j < S - 1; ++j) {
-        if constexpr (!g1) reads(rs);
-        bar();
-        if (has_next) { issue(j, ws); ws = nxt(ws); }
-        if constexpr (g1) reads(rs);
-        else mfmas();
-        // the next step's stage: with a next tile the ring stays S-1 deep, otherwise it drains
-        const int younger = has_next ? S - 2 : S - 3 - j;
-        if (younger >= 2) wait_vm<2 * DPS>();
-        else if (younger == 1) wait_vm<DPS>();
-        else wait_vm<0>();
-        bar();
-        if constexpr (g1) mfmas();
-        rs = nxt(rs);
-      }
-    };
-    wait_vm<(S - 2) * DPS>();                    // stage 0 of the first tile
-    bar();
-    for (int ti = 0; ti < my_tiles; ++ti) {
-      has_next = ti + 1 < my_tiles;
-      ti_next = ti + 1;
-      zero_acc();
-      if (wave >= 4) kloop(std::true_type{});
-      else kloop(std::false_type{});
-      char* stg = nullptr;
-      if constexpr (kStage) {
-        bar();                                     // waves 4-7 are done reading the last stage
-        stg = smem + (rs == 0 ? S - 1 : rs - 1) * STAGE + wave * 4096;
-      }
-      epilogue(ct, stg, tile0 + ti * nxb);
-      if (has_next) ct = tile_coords(tile0 + (ti + 1) * nxb);
-      else ws = rs;
-    }
-    return;
-  }
+  static_assert(!PP || M16, "the ping-pong schedule exists in its 16x16x32 form only (the 32x32x16 one measured 2 % slower)");
   for (int ti = 0; ti < my_tiles; ++ti) {
     const bool has_next = ti + 1 < my_tiles;
     zero_acc();
@@ -724,28 +640,25 @@ static bool big_cfg_ok(const GemmP& p, const BigCfg& c) {
 }
 
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
-  static const char* off = getenv("DFW_GEMM_NOBIG");
-  static const char* force = getenv("DFW_BIG_CFG");   // experiments: "256x128x64"
-  if (off) return false;
+  if (!cfg().big_kernels) return false;
   if (p.splitk > 1 || (p.N % 8) != 0) return false;
   if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.res_f32) return false;
-  if (force) {
-    BigCfg c;
-    c.occ = 1;
-    if (sscanf(force, "%dx%dx%dx%d", &c.bm, &c.bn, &c.bk, &c.occ) >= 3 && big_cfg_ok(p, c)) {
-      bm = c.bm; bn = c.bn; bk = c.bk + (c.occ == 2 ? 1000 : 0);
+  if (cfg().big_bm) {      // sweeps: a forced configuration where it fits
+    const BigCfg c = {cfg().big_bm, cfg().big_bn, cfg().big_bk, 1};
+    const bool known = (c.bm == 256 && c.bn == 256 && c.bk == 32) || (c.bm == 512 && c.bn == 128 && c.bk == 32) ||
+                       (c.bm == 256 && c.bn == 128 && (c.bk == 32 || c.bk == 64));
+    if (known && big_cfg_ok(p, c)) {
+      bm = c.bm; bn = c.bn; bk = c.bk;
       return true;
     }
   }
   static const BigCfg wide[] = {{256, 256, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
   static const BigCfg narrow[] = {{512, 128, 32, 1}, {256, 128, 64, 1}, {256, 128, 32, 1}};
-  // DFW_BIG_RAGGED=1: N % 64 == 0 shapes (the UNet's 320 / 960 columns) on the 128-wide tiles too.  Measured neutral
-  // on MI355X (44.01 vs 43.98 ms per step: the half-empty last column tile costs what the bigger tile gains), so
-  // gemm.hip's cost-model tiles keep them by default.
-  static const char* rag = getenv("DFW_BIG_RAGGED");
-  // ... except where the half-empty tile is a small share of the columns (<= 10 %: N = 960 of the 64x64-level fused QKV
-  // and its data gradient -- 38.7 vs 51.4 us on 32768 x 960 x 320, scratch/sweep_big.py; N = 320 wastes 20 % and stays).
-  const bool rag_ok = rag || ((p.N + 127) / 128 * 128 - p.N) * 10 <= p.N;
+  // N % 64 == 0 shapes (the UNet's 320 / 960 columns) on the 128-wide tiles: measured neutral on the whole (44.01 vs 43.98 ms
+  // per step: the half-empty last column tile costs what the bigger tile gains), so gemm.hip's cost-model tiles keep them --
+  // except where the half-empty tile is a small share of the columns (<= 10 %: N = 960 of the 64x64-level fused QKV and its
+  // data gradient -- 38.7 vs 51.4 us on 32768 x 960 x 320, scratch/sweep_big.py; N = 320 wastes 20 % and stays).
+  const bool rag_ok = ((p.N + 127) / 128 * 128 - p.N) * 10 <= p.N;
   if ((p.N % 128) == 0 || ((p.N % 64) == 0 && p.N > 128 && !p.geglu && rag_ok)) {
     const BigCfg* list = (p.N % 256) == 0 ? wide : narrow;
     // Short-K linears whose 256 x 256 tile count quantises badly over the 256 CUs (2048 x 10240 x 1280 GEGLU: 320 tiles =
@@ -766,24 +679,12 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
         return true;
       }
   }
-  // Experiment (DFW_BIG_SMALL=1): the UNet's K = 320...1280 projections on 128x128 tiles, two
-  // workgroups per CU, the same 4-stage ring -- six stages in flight per CU instead of gemm.hip's two.
-  // Measured neutral (3.19 vs 3.16 ms over the 110 linear launches of a step, scratch/bench_lin.py):
-  // those launches sit at 20-25 us whatever the staging depth (2.5 tile rounds of 5-20 K-steps each,
-  // ramp and tail dominate), so gemm.hip's cost-model tiles stay the default for them.
-  static const char* small = getenv("DFW_BIG_SMALL");
-  static const BigCfg sm = {128, 128, 32, 2};
-  if (small && small[0] == '1' && p.taps == 1 && !p.geglu && big_cfg_ok(p, sm)) {
-    bm = 128; bn = 128; bk = 32 + 1000;
-    return true;
-  }
   return false;
 }
 
 int gemm_big_gn_chunks(const GemmP& p) {
   int bm = 0, bn = 0, bk = 0;
   if (p.gn_groups <= 0 || p.taps != 9 || p.geglu || !gemm_big_eligible(p, bm, bn, bk)) return 0;
-  if (bk > 1000) return 0;                                        // 2-workgroup variant has no staging
   if ((size_t)(bm + bn) * bk * 2 < 8 * 4096) return 0;            // staged epilogue needs a 32 KiB slot
   if (p.N % p.gn_groups) return 0;
   const int cpg = p.N / p.gn_groups;
@@ -796,20 +697,12 @@ int launch_gemm_big(const GemmP& p, hipStream_t st) {
   int bm = 0, bn = 0, bk = 0;
   if (!gemm_big_eligible(p, bm, bn, bk)) return DFW_ESHAPE;
   const bool bf = p.dtype_bf16 != 0;
-  if (bk > 1000 && bm == 128) return bf ? launch_big<__bf16, 128, 128, 32, 4, 2>(p, st) : launch_big<_Float16, 128, 128, 32, 4, 2>(p, st);
-  if (bk > 1000) return bf ? launch_big<__bf16, 256, 128, 32, 3, 2>(p, st) : launch_big<_Float16, 256, 128, 32, 3, 2>(p, st);
-  static const char* nopp = getenv("DFW_BIG_NOPP");   // A/B switch for the ping-pong schedule
-  static const char* m32 = getenv("DFW_BIG_M32");     // A/B switch: 32x32x16 MFMA in the ping-pong kernels
-  if (bm == 256 && bn == 256) {
-    if (nopp) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1>(p, st);
-    if (m32) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true>(p, st);
+  // 256 x 256 and 512 x 128: ping-pong schedule with v_mfma_f32_16x16x32 (A/B history in DESIGN.md section 3: +2 % each
+  // against the in-phase schedule and against 32x32x16 in the same schedule; those instantiations are gone)
+  if (bm == 256 && bn == 256)
     return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true, true>(p, st);
-  }
-  if (bm == 512) {
-    if (nopp) return bf ? launch_big<__bf16, 512, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1>(p, st);
-    if (m32) return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true>(p, st);
+  if (bm == 512)
     return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true, true>(p, st);
-  }
   if (bk == 64) return bf ? launch_big<__bf16, 256, 128, 64, 3, 1>(p, st) : launch_big<_Float16, 256, 128, 64, 3, 1>(p, st);
   return bf ? launch_big<__bf16, 256, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 128, 32, 4, 1>(p, st);
 }

@@ -1,7 +1,6 @@
 // GroupNorm(+SiLU) and LayerNorm on NHWC / [rows][C] activations for gfx950.
 // HBM-bound: 16-byte vector access, fp32 statistics, deterministic reductions (no atomics).
 #include "common.h"
-#include <stdlib.h>
 
 namespace dfw {
 
@@ -291,13 +290,10 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   p.mr = p.part + (size_t)a->B * chunks * a->groups * 2;
   p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.ldy = a->ldy;
   p.chunks = chunks; p.ppc = ppc; p.eps = a->eps; p.silu = a->silu;
-  // Non-temporal stores make this kernel 15-30 % faster in isolation (4.7 -> 5.5 TB/s) but the step no
-  // faster (47.2 vs 47.0 ms, same box): the consumer conv then misses L2 / Infinity Cache on its first
-  // touch.  Opt-in for callers whose consumer is not the next kernel.
-  static const char* fwd = getenv("DFW_GN_FWD");   // A/B: front-to-back walk
-  p.rev = fwd ? 0 : 1;
-  static const char* nt = getenv("DFW_GN_NT");
-  p.nt = (nt && nt[0] == '1') ? 1 : 0;
+  // back-to-front walk (see gn_stats_kernel); plain stores: non-temporal ones made this kernel 15-30 % faster in isolation
+  // (4.7 -> 5.5 TB/s) but the step no faster (47.2 vs 47.0 ms): the consumer conv then misses L2 / Infinity Cache
+  p.rev = 1;
+  p.nt = 0;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds1 = (size_t)slots * a->C * 2 * sizeof(float);
   if (lds1 > 64 * 1024) return DFW_ESHAPE;

@@ -136,7 +136,7 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
     gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x -- applied
-    by dfw_groupnorm first, or (fuse_gn_in=True, or DFW_GN_FUSE=1 in the environment) inside the conv
+    by dfw_groupnorm first, or (fuse_gn_in=True, or ops.GN_FUSE_DEFAULT = True) inside the conv
     kernel where the library supports that for the shape.  The fused form is off by default: measured
     on MI355X it does not pay yet (conv_patch.hip, GNIN).
     out_f32: NHWC fp32 output, and `residual` may be fp32 -- the fp32 residual stream (x + branch summed and stored
@@ -144,7 +144,7 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     assert x.dim() == 4 and x.stride(3) == 1 and x.is_contiguous()
     B, Hi, Wi, Cin = x.shape
     if fuse_gn_in is None:
-        fuse_gn_in = _GN_FUSE_DEFAULT
+        fuse_gn_in = GN_FUSE_DEFAULT
     if gn_in is not None and not (fuse_gn_in and not out_f32 and x.dtype != torch.float32
                                   and (residual is None or residual.dtype == x.dtype)
                                   and _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk)):
@@ -198,7 +198,7 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     return out
 
 
-_GN_FUSE_DEFAULT = os.environ.get("DFW_GN_FUSE", "0") == "1"
+GN_FUSE_DEFAULT = False   # module switch for A/B runs; measured: the fused form does not pay
 
 
 def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):

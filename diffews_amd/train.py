@@ -754,6 +754,18 @@ class UNetTrainer:
             out = _QueryPass.apply(prm, self, ref, sample, timestep, encoder_hidden_states)
         return UNet2DConditionOutput(sample=out) if return_dict else (out,)
 
+    def make_reducer(self, bucket_elems=54_000_000, comm_dtype=torch.float32, group=None, **kw):
+        """GradBucketReducer over this trainer's flat gradient buffer (DDP's role, T:1226-1228): pass it to
+        forward_backward(reducer=...) -- or set `self.reducer` for the autograd call surface -- and call .finish() before
+        the optimizer step; .finish() returns the loss averaged over the ranks (T:1387)."""
+        spec = {}
+        for name, (off, shape) in self.P.spec.items():
+            n = 1
+            for d in shape:
+                n *= d
+            spec[name] = (off, n)
+        return GradBucketReducer(self.P.grad_buf, spec, bucket_elems=bucket_elems, comm_dtype=comm_dtype, group=group, **kw)
+
     # ------------------------------------------------------------------ optimizer (T:1186-1194, T:1217-1223, T:1393-1394)
     def grad_sumsq(self):
         return ob.sumsq(self.P.grad)

@@ -312,8 +312,8 @@ class MyUNet2DConditionModel:
             t.kv_slice = (off, t.w_kv2.shape[0])
             off += t.w_kv2.shape[0]
         self.kv_w_all = torch.cat(kvw, 0).contiguous()
-        # fold_conditioning() also folds attn2 on the constant prompt (DFW_NO_ATTN2_FOLD=1: A/B switch)
-        self.fold_attn2 = os.environ.get("DFW_NO_ATTN2_FOLD") is None
+        # fold_conditioning() also folds attn2 on the constant prompt (set False before folding for an A/B run)
+        self.fold_attn2 = True
 
     def _resnets_with_prefix(self):
         for i, blk in enumerate(self.down):

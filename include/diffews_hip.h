@@ -14,7 +14,9 @@
  *     explicit element stride per row, images and latents at the pipeline boundary are NCHW fp32;
  *   - launches are asynchronous on the hipStream_t passed in (graph-capturable);
  *   - return value: 0 on success, a negative DFW_E* code for a rejected argument, or a positive
- *     hipError_t from the launch; no C++ exception crosses the boundary; no global mutable state.
+ *     hipError_t from the launch; no C++ exception crosses the boundary;
+ *   - no global mutable state and nothing read from the environment, with ONE explicit exception: the process-wide
+ *     tuning record of dfw_configure() below (defaults = the measured-best plans; meant for sweeps and A/B runs).
  */
 #ifndef DIFFEWS_HIP_H
 #define DIFFEWS_HIP_H
@@ -40,6 +42,21 @@ enum {
 
 int dfw_version(void);
 const char* dfw_error_string(int code);
+
+/* Process-wide kernel-plan switches.  Every field's 0 value is NOT special: pass a record obtained from
+ * dfw_get_config() with the fields of interest changed.  dfw_configure(NULL) restores the defaults.  Call it before the
+ * launches it should affect; it is not synchronised against concurrent launches from other threads. */
+typedef struct {
+  int32_t conv_patch;        /* conv_patch_kernel: 0 off, 1 (default) the N = 128 conv3x3 layers, 2 also the N % 256 == 0 ones */
+  int32_t big_kernels;       /* 1 (default) gemm_big_kernel where eligible; 0: gemm_kernel tiles only */
+  int32_t big_bm, big_bn, big_bk;   /* != 0: force this gemm_big configuration where it fits (sweeps), e.g. 256, 128, 64 */
+  int32_t gemm_bm, gemm_bn;  /* != 0: force this gemm_kernel tile (128x128, 128x64, 64x64) instead of the cost model */
+  int32_t fsa_pipelined;     /* 1 (default) software-pipelined attention forward for pre-scaled q and > 1024 query rows */
+  int32_t fsa_key_split;     /* 1 (default) split the bank readers' key range when a workspace is passed; 0 never */
+  int32_t fsa_force_splits;  /* != 0: this split count for eligible launches (forward and dQ) */
+} dfw_config;
+int dfw_configure(const dfw_config* cfg);
+void dfw_get_config(dfw_config* out);
 
 /* HOST function: number of memset nodes in a captured hipGraph_t (child graphs included), or a negative DFW_E* code;
  * *n_nodes (optional) receives the node count.  The pipeline-owned step graph (pipeline.run_episodes(captured=True))

@@ -1,6 +1,9 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffews_amd import ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _cfg
+_cfg.apply_env_config()
 shapes = {"vae512": (12, 512, 512, 128, 128), "vae256": (12, 256, 256, 256, 256), "vae128": (12, 128, 128, 512, 512),
           "unet64": (4, 64, 64, 320, 320), "unet32": (4, 32, 32, 640, 640), "unet16": (4, 16, 16, 1280, 1280),
           "unet8": (4, 8, 8, 1280, 1280), "dec512": (4, 512, 512, 128, 128), "b1_512": (1, 512, 512, 128, 128), "b2_512": (2, 512, 512, 128, 128),

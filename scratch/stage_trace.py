@@ -5,7 +5,9 @@ UNet's lock-step pass and the VAE decoder) two numbers, relative L2 against the 
   cum    engine running end to end from the pipeline inputs (error accumulated so far);
   local  the engine's stage fed the ORACLE's input of that stage rounded once to the storage dtype (what one
          stage adds on exact input: the floor of a 16-bit-storage pipeline is the root-sum-square of these).
-Usage (GPU box):  python scratch/stage_trace.py [fp16|bf16] [res] > gpurun_out/stage_trace_fp16.txt
+With a third argument "f32s" the engines run with residual_dtype=torch.float32 (fp32 residual stream): `local` is then the
+stage on the oracle's UNROUNDED input -- what remains is the 16-bit rounding of the stage's MFMA operands alone.
+Usage (GPU box):  python scratch/stage_trace.py [fp16|bf16] [res] [f32s] > gpurun_out/stage_trace_fp16.txt
 """
 import os
 import sys
@@ -24,6 +26,7 @@ from oracle.vae import OracleVAE                                         # noqa:
 
 dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float16
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+f32s = len(sys.argv) > 3 and sys.argv[3] == "f32s"
 b, nshot = 2, 1
 torch.backends.cudnn.allow_tf32 = False
 torch.backends.cuda.matmul.allow_tf32 = False
@@ -40,6 +43,8 @@ ou = OracleUNet(**kwf(ucfg)); ou.load_state_dict(usd); ou = ou.eval().cuda()
 ov = OracleVAE(**kwf(vcfg)); ov.load_state_dict(vsd); ov = ov.eval().cuda()
 pipe = MarigoldPipelineRGBLatentNoise(U.MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt), V.AutoencoderKL(vcfg, vsd, torch_dtype=dt),
                                       DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
+if f32s:
+    pipe.set_residual_dtype(torch.float32)
 
 # ---- oracle side: record (input, output) of every stage module, in call order
 orec = []
@@ -71,7 +76,8 @@ engine_calls = list(erec)
 for c, o in originals.items():
     c.__call__ = o
 
-print(f"# stage trace: {str(dt)} storage, {res}x{res}, b={b}, {nshot}-shot; relative L2 vs fp32 oracle on device")
+print(f"# stage trace: {str(dt)} storage, residual stream {'fp32' if f32s else str(dt)}, {res}x{res}, b={b}, {nshot}-shot; "
+      "relative L2 vs fp32 oracle on device")
 n_sup = b * nshot
 # oracle call order: encoder x3 (ref imgs, query imgs, masks: P:649-651 order in OP.single_infer), UNet ref pass,
 # UNet query pass, decoder.  engine order: ONE encoder pass over [sup ; masks ; query], ONE lock-step UNet, decoder.
@@ -89,7 +95,7 @@ assert len(dec_o) == n_dec_stage == len(dec_e), (len(dec_o), n_dec_stage, len(de
 
 def local_err(eng, o_in, o_out, extra=None):
     """engine stage on the oracle's input (rounded once) vs the oracle's output"""
-    x = nhwc(o_in).to(dt)
+    x = nhwc(o_in).to(torch.float32 if f32s else dt)
     y = originals[type(eng)](eng, x, *(extra or ()))
     return rel(nchw(y), o_out)
 

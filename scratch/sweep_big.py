@@ -4,6 +4,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from diffews_amd import ops
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _cfg
+    _cfg.apply_env_config()
     tag = os.environ.get("TAG", "")
     def t(fn):
         for _ in range(2): fn()
@@ -32,7 +35,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             print(f"conv {tag} {B*H*H} {Co} {9*Ci} ERR {str(e)[:40]}"); continue
         print(f"conv {tag} {B*H*H} {Co} {9*Ci} {us:.1f}", flush=True)
 else:
-    for tag, env in [("default", {}), ("nobig", {"DFW_GEMM_NOBIG": "1"}), ("256x256x32", {"DFW_BIG_CFG": "256x256x32"}),
-                     ("512x128x32", {"DFW_BIG_CFG": "512x128x32"}), ("256x128x64", {"DFW_BIG_CFG": "256x128x64"}),
-                     ("256x128x32", {"DFW_BIG_CFG": "256x128x32"})]:
+    for tag, env in [("default", {}), ("nobig", {"DFW_CFG": "big_kernels=0"}), ("256x256x32", {"DFW_CFG": "big_bm=256,big_bn=256,big_bk=32"}),
+                     ("512x128x32", {"DFW_CFG": "big_bm=512,big_bn=128,big_bk=32"}), ("256x128x64", {"DFW_CFG": "big_bm=256,big_bn=128,big_bk=64"}),
+                     ("256x128x32", {"DFW_CFG": "big_bm=256,big_bn=128,big_bk=32"})]:
         subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, TAG=tag, **env))

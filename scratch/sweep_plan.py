@@ -5,7 +5,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from diffews_amd import ops
-    tile = os.environ["DFW_GEMM_TILE"]
+    tile = os.environ["SWEEP_TILE"]
+    from diffews_amd import _lib
+    _lib.configure(big_kernels=0, gemm_bm=int(tile.split("x")[0]), gemm_bn=int(tile.split("x")[1]))
     convs = [(8, 64, 320, 320), (8, 64, 640, 320), (8, 64, 960, 320), (8, 32, 640, 640), (8, 32, 320, 640), (8, 32, 1280, 640),
              (8, 32, 1920, 640), (8, 32, 960, 640), (8, 16, 1280, 1280), (8, 16, 640, 1280), (8, 16, 2560, 1280), (8, 16, 1920, 1280),
              (8, 8, 1280, 1280), (8, 8, 2560, 1280)]
@@ -39,5 +41,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             print(f"lin {tile} {M} {N} {K} {sk} {us:.1f}", flush=True)
 else:
     for tile in ("128x128", "128x64", "64x64"):
-        env = dict(os.environ, DFW_GEMM_TILE=tile, DFW_GEMM_NOBIG="1")
+        env = dict(os.environ, SWEEP_TILE=tile)
         subprocess.run([sys.executable, __file__, "child"], env=env)

@@ -554,7 +554,8 @@ def test_gradient_buckets_are_reduced_after_their_last_writer(hip_lib):
     tr = UNetTrainer(ucfg, usd, torch_dtype=dtype)
     args = (z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda())
     tr.forward_backward(*args)                       # warm-up (lazy derived weights)
-    tr.P.grad_buf.fill_(float("nan"))                # poison: a too-early snapshot would contain NaNs
+    for name in tr.P.spec:                           # poison every parameter's gradient: a too-early snapshot would hold NaNs
+        tr.P.g(name).fill_(float("nan"))             # (the 64-float alignment pads between entries stay zero, as always)
     snaps = {}
     spec = {k: (off, max(1, int(torch.tensor(shape).prod()))) for k, (off, shape) in tr.P.spec.items()}
     red = GradBucketReducer(tr.P.grad_buf, spec, bucket_elems=1 << 21, world_size=2,

@@ -133,8 +133,9 @@ def test_tiny_episode_against_committed_golden(hip_lib, dt):
         assert d.mean() < (1.0 if dt == torch.float16 else 4.0)
 
 
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-def test_fullsize_episode_against_oracle_on_device(hip_lib, dt):
+@pytest.mark.parametrize("dt,rdt", [(torch.float16, None), (torch.bfloat16, None), (torch.float16, torch.float32)],
+                         ids=["fp16", "bf16", "fp16-fp32stream"])
+def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     """The EXACT BASELINE.json shapes -- configs[1] (512x512, 1-shot, batch 4), configs[2] (512x512, 5-shot,
     batch 2: 6-image in-context latent, 24 576 keys at the 64x64 level) and configs[0]'s resolution (256x256,
     1-shot, batch 1) -- SD-2.1 UNet + SD VAE, against the fp32 ORACLE itself: the oracle is plain torch, so on
@@ -144,7 +145,11 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt):
     Tolerance on the parity tensor z0 (P:769): 1.25 x the measured error, which the per-stage trace
     (profiles/r02_stage_trace_*.txt) shows to be the floor of ANY 16-bit-storage pipeline:
     every residual-level stage adds exactly one storage rounding (2.9e-4 fp16 / 2.4e-3 bf16) and nothing else;
-    measured 1.45e-3 fp16 / 1.18e-2 bf16."""
+    measured 1.45e-3 fp16 / 1.18e-2 bf16.
+    fp16-fp32stream: residual_dtype=torch.float32 -- the residual stream summed and stored in fp32, MFMA operands fp16.
+    north_star's bar is 1e-3; measured 1.005e-3 / 0.995e-3 / 1.048e-3 at the three shapes: what remains is the fp16 rounding
+    of the conv / GEMM OPERANDS (one per branch input, profiles/r03_stage_trace_fp16_f32stream.txt), not of the stream.
+    Tolerance 1.1 x the largest measured value."""
     from diffews_amd import config, weights
     from diffews_amd.episodes import make_episode_batch
     from diffews_amd.pipeline import MarigoldPipelineRGBLatentNoise
@@ -166,16 +171,18 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt):
         ou = OracleUNet(**kwf(ucfg)); ou.load_state_dict(usd); ou = ou.eval().cuda()
         ov = OracleVAE(**kwf(vcfg)); ov.load_state_dict(vsd); ov = ov.eval().cuda()
         pipe = MarigoldPipelineRGBLatentNoise(
-            MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt), AutoencoderKL(vcfg, vsd, torch_dtype=dt),
+            MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt, residual_dtype=rdt),
+            AutoencoderKL(vcfg, vsd, torch_dtype=dt, residual_dtype=rdt),
             DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
-        tol = 1.8e-3 if dt == torch.float16 else 1.5e-2
+        assert pipe.residual_dtype == (rdt or dt)
+        tol = (1.15e-3 if rdt == torch.float32 else 1.8e-3) if dt == torch.float16 else 1.5e-2
         for b, nshot, res in ((4, 1, 512), (2, 5, 512), (1, 1, 256)):
             bt = make_episode_batch(b, nshot, res, seed=40 + nshot + b, device="cuda")
             with torch.no_grad():
                 ref = OP.single_infer(ou, ov, bt["support_imgs"], bt["query_img"], bt["support_masks"], te.cuda())
             r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"])
             assert rel(r["z0"], ref["z0"]) < tol, (b, nshot, res, rel(r["z0"], ref["z0"]))
-            print(f"[parity] {str(dt):15s} b={b} {nshot}-shot {res}x{res}: z0 rel L2 {rel(r['z0'], ref['z0']):.3e}")
+            print(f"[parity] {str(dt):15s} stream {str(rdt or dt):15s} b={b} {nshot}-shot {res}x{res}: z0 rel L2 {rel(r['z0'], ref['z0']):.3e}")
             # decoder output in [0, 255] (P:790-795): mean absolute difference in uint8 levels
             seg_ref = ref["seg"].clip(0, 255)
             seg = (r["dec"].clip(-1, 1) * 0.5 + 0.5) * 255
@@ -233,3 +240,113 @@ def test_fullsize_other_resolutions_against_oracle_on_device(hip_lib):
             assert rel(r["z0"], ref["z0"]) < 2.0e-3, (H, W, rel(r["z0"], ref["z0"]))
     finally:
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+def _fullsize_train_case(dt, nshot, res, sample_vae, seed):
+    """One training micro-step at SD-2.1 size: UNetTrainer (lock-step forward, hand-written backward) vs torch autograd of
+    the fp32 ORACLE's two-pass graph run on the device (banks keep the graph, T:1374-1384).  Returns the measured errors."""
+    import torch.nn.functional as F
+    from diffews_amd import config, weights
+    from diffews_amd.episodes import make_episode_batch
+    from diffews_amd.train import UNetTrainer
+    from diffews_amd.vae import AutoencoderKL
+    from oracle.unet import OracleUNet
+    from oracle.vae import OracleVAE
+    ucfg, vcfg = config.get("sd21_unet"), config.get("sd_vae")
+    kwf = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
+    usd = weights.synthetic_unet_state_dict(ucfg, round_to=dt)
+    g = torch.Generator().manual_seed(seed)
+    ehs = torch.randn(1, 77, ucfg["cross_attention_dim"], generator=g).to(dt).float().cuda()      # 77-token prompt (T:1368)
+    h = res // 8
+    out = {}
+    if sample_vae:
+        # the frozen VAE's SAMPLED encodes (T:1347-1358): engine moments + noise from a device generator vs the oracle's
+        # moments + the same noise (same seed, shape, device, dtype => the same stream)
+        vsd = weights.synthetic_vae_state_dict(vcfg, round_to=dt)
+        bt = make_episode_batch(1, nshot, res, seed=seed, device="cuda")
+        qmask = (bt["query_mask"].float()[:, None].repeat(1, 3, 1, 1) * 2 - 1).contiguous()
+        srcs = [torch.cat([bt["support_imgs"], bt["query_img"]]).contiguous(), bt["support_masks"], qmask]
+        vae = AutoencoderKL(vcfg, vsd, torch_dtype=dt)
+        lat = vae.encode(srcs).latent_dist.sample(generator=torch.Generator(device="cuda").manual_seed(77)) * 0.18215
+        ov = OracleVAE(**kwf(vcfg)); ov.load_state_dict(vsd); ov = ov.eval().cuda()
+        with torch.no_grad():
+            mom = ov.quant_conv(ov.encoder(torch.cat(srcs)))
+        mean, logvar = torch.chunk(mom, 2, dim=1)
+        noise = torch.randn(mean.shape, generator=torch.Generator(device="cuda").manual_seed(77), device="cuda", dtype=mean.dtype)
+        lat_o = (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise) * 0.18215
+        out["latents"] = rel(lat, lat_o)
+        s = nshot
+        z_refcat, z_tag, target = torch.cat([lat[:s], lat[s + 1:2 * s + 1]], 1), lat[s:s + 1], -lat[2 * s + 1:]
+        zo_refcat, zo_tag, target_o = torch.cat([lat_o[:s], lat_o[s + 1:2 * s + 1]], 1), lat_o[s:s + 1], -lat_o[2 * s + 1:]
+        del ov, vae, mom
+    else:
+        z_refcat = (torch.randn(nshot, 8, h, h, generator=g) * 0.5).cuda()
+        z_tag = (torch.randn(1, 4, h, h, generator=g) * 0.5).cuda()
+        target = (torch.randn(1, 4, h, h, generator=g) * 0.5).cuda()
+        zo_refcat, zo_tag, target_o = z_refcat, z_tag, target
+    torch.cuda.empty_cache()
+    # ---- oracle: fp32 autograd on the device (checker only)
+    ou = OracleUNet(**kwf(ucfg)); ou.load_state_dict(usd); ou = ou.train().cuda()
+    ou.clear_attn_bank()
+    ou(zo_refcat, 1, ehs.repeat(nshot, 1, 1), is_target=False)
+    pred_o = ou(zo_tag, 1, ehs, is_target=True)
+    ou.clear_attn_bank()
+    loss_o = F.mse_loss(pred_o.float(), target_o.float())
+    loss_o.backward()
+    gref = {k: p.grad.detach().cpu() for k, p in ou.named_parameters() if p.grad is not None}
+    pred_o, loss_o = pred_o.detach().cpu(), float(loss_o)
+    del ou
+    torch.cuda.empty_cache()
+    # ---- engine
+    tr = UNetTrainer(ucfg, usd, torch_dtype=dt, loss_scale=1.0 if dt == torch.bfloat16 else 1024.0, dynamic_loss_scale=False)
+    loss, pred = tr.forward_backward(z_refcat, z_tag, target, 1, ehs)
+    gd = {k: v.cpu() for k, v in tr.grad_dict().items()}
+    assert set(gd) == set(gref), set(gd) ^ set(gref)
+    out["pred"] = rel(pred, pred_o)
+    out["loss"] = abs(float(loss) - loss_o) / abs(loss_o)
+    per = sorted(((rel(gd[k], gref[k]), k, float(gref[k].norm())) for k in gref), reverse=True)
+    out["worst"] = per[:5]
+    keys = sorted(gref)
+    flat = torch.cat([gd[k].float().reshape(-1) for k in keys])
+    flat_o = torch.cat([gref[k].reshape(-1) for k in keys])
+    out["flat_rel"] = rel(flat, flat_o)
+    out["cos"] = float(torch.nn.functional.cosine_similarity(flat.double(), flat_o.double(), dim=0))
+    out["finite"] = bool(torch.isfinite(flat).all())
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.parametrize("dt,nshot,sample_vae", [(torch.bfloat16, 7, False), (torch.float16, 7, False), (torch.bfloat16, 2, True)],
+                         ids=["bf16-7shot", "fp16-7shot", "bf16-2shot-sampled-vae"])
+def test_fullsize_training_step_against_oracle_autograd(hip_lib, dt, nshot, sample_vae):
+    """BASELINE configs[4] at its real size: ONE 512x512 micro-step of the SD-2.1 UNet (865.9 M parameters) -- 7 shots
+    (32 768 keys at the 64x64 level: the key-split forward + dQ plans, the 256-wide TN-GEMM tiles, first-touch gradient
+    writes), or 2 shots fed by the frozen VAE's SAMPLED encodes -- against torch autograd of the fp32 oracle on the device
+    (TF32 off).  Checked: loss, pred, the flat gradient (relative L2, cosine) and every parameter tensor; the five worst
+    tensors are printed on every run.  Tolerances: 1.25 x the values measured on MI355X (recorded in DESIGN.md section 4)."""
+    prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        r = _fullsize_train_case(dt, nshot, 512, sample_vae, seed=60 + nshot)
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
+    print(f"[train-parity] {str(dt):15s} {nshot}-shot sampled_vae={sample_vae}: pred {r['pred']:.3e}  loss {r['loss']:.3e}  "
+          f"flat grad rel L2 {r['flat_rel']:.3e}  cos {r['cos']:.6f}" + (f"  latents {r['latents']:.3e}" if sample_vae else ""))
+    for e, k, n in r["worst"]:
+        print(f"[train-parity]    worst tensor {k:70s} rel L2 {e:.3e}  |g_ref| {n:.3e}")
+    bf = dt == torch.bfloat16
+    assert r["finite"]
+    assert r["pred"] < (TRAIN_TOL["pred_bf16"] if bf else TRAIN_TOL["pred_fp16"]), r["pred"]
+    assert r["loss"] < (TRAIN_TOL["loss_bf16"] if bf else TRAIN_TOL["loss_fp16"]), r["loss"]
+    assert r["flat_rel"] < (TRAIN_TOL["flat_bf16"] if bf else TRAIN_TOL["flat_fp16"]), r["flat_rel"]
+    assert r["cos"] > (TRAIN_TOL["cos_bf16"] if bf else TRAIN_TOL["cos_fp16"]), r["cos"]
+    assert r["worst"][0][0] < (TRAIN_TOL["tensor_bf16"] if bf else TRAIN_TOL["tensor_fp16"]), r["worst"][0]
+    if sample_vae:
+        assert r["latents"] < TRAIN_TOL["latents_bf16"], r["latents"]
+
+
+# measured on MI355X (gpurun_out/r03_train_parity.log) x 1.25 -- see DESIGN.md section 4
+TRAIN_TOL = dict(pred_bf16=3e-2, pred_fp16=6e-3, loss_bf16=5e-2, loss_fp16=1e-2, flat_bf16=0.10, flat_fp16=0.02,
+                 cos_bf16=0.995, cos_fp16=0.9998, tensor_bf16=0.5, tensor_fp16=0.2, latents_bf16=3e-2)

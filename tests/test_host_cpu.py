@@ -47,7 +47,8 @@ def test_struct_layouts_match_header():
                        ("dfw_conv_small_args", _lib.ConvSmallArgs), ("dfw_gemm_tn_args", _lib.GemmTnArgs),
                        ("dfw_groupnorm_bwd_args", _lib.GroupNormBwdArgs), ("dfw_layernorm_bwd_args", _lib.LayerNormBwdArgs),
                        ("dfw_fsa_bwd_args", _lib.FsaBwdArgs), ("dfw_xattn_bwd_args", _lib.XattnBwdArgs),
-                       ("dfw_attn_bwd_args", _lib.AttnBwdArgs), ("dfw_adamw_args", _lib.AdamWArgs), ("dfw_image_args", _lib.ImageArgs)):
+                       ("dfw_attn_bwd_args", _lib.AttnBwdArgs), ("dfw_adamw_args", _lib.AdamWArgs), ("dfw_image_args", _lib.ImageArgs),
+                       ("dfw_config", _lib.Config)):
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", hdr).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -65,7 +66,7 @@ def test_sizeof_structs_against_compiler(tmp_path):
     src = tmp_path / "sz.c"
     names = ["dfw_gemm_args", "dfw_fsa_args", "dfw_xattn_args", "dfw_groupnorm_args", "dfw_layernorm_args",
              "dfw_conv_small_args", "dfw_gemm_tn_args", "dfw_groupnorm_bwd_args", "dfw_layernorm_bwd_args",
-             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_attn_bwd_args", "dfw_adamw_args", "dfw_image_args"]
+             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_attn_bwd_args", "dfw_adamw_args", "dfw_image_args", "dfw_config"]
     src.write_text('#include <stdio.h>\n#include "diffews_hip.h"\nint main(){' +
                    "".join(f'printf("%zu ", sizeof({n}));' for n in names) + 'return 0;}\n')
     exe = tmp_path / "sz"
@@ -74,7 +75,23 @@ def test_sizeof_structs_against_compiler(tmp_path):
     assert sizes == [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.FsaArgs, _lib.XattnArgs, _lib.GroupNormArgs,
                                                 _lib.LayerNormArgs, _lib.ConvSmallArgs, _lib.GemmTnArgs,
                                                 _lib.GroupNormBwdArgs, _lib.LayerNormBwdArgs, _lib.FsaBwdArgs,
-                                                _lib.XattnBwdArgs, _lib.AttnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs)]
+                                                _lib.XattnBwdArgs, _lib.AttnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs, _lib.Config)]
+
+
+def test_library_reads_nothing_from_the_environment():
+    """include/diffews_hip.h: the only process-wide state is the record of dfw_configure(); no getenv in the kernels'
+    host code (21 function-local environment switches lived there until round 3)."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "diffews_amd", "csrc", "*")):
+        with open(f) as fh:
+            assert "getenv" not in fh.read(), f
+    from diffews_amd import _lib as L
+    d0 = L.configure()
+    assert d0["conv_patch"] == 1 and d0["big_kernels"] == 1 and d0["fsa_pipelined"] == 1 and d0["gemm_bm"] == 0
+    assert L.configure(conv_patch=2, gemm_bm=128, gemm_bn=64)["conv_patch"] == 2
+    with pytest.raises(RuntimeError):
+        L.configure(gemm_bm=96, gemm_bn=96)
+    assert L.configure() == d0
 
 
 def test_product_never_imports_oracle():
