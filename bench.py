@@ -66,7 +66,9 @@ def cpu_baseline(model_blobs, res, nshot, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("DFW_CPU_THREADS", str(cores)))))   # every core of this job's share
+    # the box's CPU share for a one-GPU job is 16 cores (a cgroup quota, invisible to sched_getaffinity): more threads than
+    # that only thrash
+    cores = max(1, min(cores, int(os.environ.get("DFW_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     kw = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
     ou = OracleUNet(**kw(ucfg)); ou.load_state_dict(usd); ou.eval()
@@ -162,6 +164,11 @@ def latest_pmc_summary():
         return os.path.basename(best[1]), json.load(f)
 
 
+def ops_hook_off():
+    from diffews_amd import ops
+    return ops.gemm_hook is None      # the instrumented roofline pass needs the eager launches
+
+
 def timed_steps(fn, warmup, steps):
     for _ in range(warmup):
         fn()
@@ -184,6 +191,7 @@ def secondary_measurements(pipe, blobs, args, res, dtype):
     from diffews_amd.metrics import AverageMeter, fold_class_ids
     out = {}
     meter = AverageMeter("coco", fold_class_ids("coco", 0), device="cuda")
+    t_sec = time.time()
 
     def infer_config(b, s, steps, warmup=2):
         bt = episodes.make_episode_batch(b, s, res, seed=300 + s, device="cuda")
@@ -208,6 +216,7 @@ def secondary_measurements(pipe, blobs, args, res, dtype):
                                    "z0 within north_star's 1e-3 of the fp32 oracle in fp16 storage (tests/test_fullsize_gpu.py)")
     finally:
         pipe.set_residual_dtype(None)
+    log(f"[secondary] fp32 stream done at +{time.time() - t_sec:.1f}s")
     # -- configs[2]
     ms, attn = infer_config(2, 5, 5)
     out["configs2_ms_per_step"] = round(ms, 3)
@@ -219,11 +228,13 @@ def secondary_measurements(pipe, blobs, args, res, dtype):
         out["configs2_attention_ms_per_step"] = round(attn[2] * 1e3, 3)
     pipe._graphs = {}
     torch.cuda.empty_cache()
+    log(f"[secondary] configs[2] done at +{time.time() - t_sec:.1f}s")
     # -- configs[4]: the training step on this one GPU
     from diffews_amd.train import UNetTrainer, poly_lr
     ucfg, usd, vcfg, vsd, te = blobs
     s = 7
     tr = UNetTrainer(ucfg, usd, torch_dtype=dtype, loss_scale=1.0 if dtype == torch.bfloat16 else 1024.0)
+    log(f"[secondary] trainer built at +{time.time() - t_sec:.1f}s")
     vae = pipe.vae
     bt = episodes.make_episode_batch(1, s, res, seed=200, device="cuda")
     qmask = (bt["query_mask"].float()[:, None].repeat(1, 3, 1, 1) * 2 - 1).contiguous()
@@ -238,7 +249,10 @@ def secondary_measurements(pipe, blobs, args, res, dtype):
 
     def train_step():
         zc, zt, tgt = encode()
-        loss, _ = tr.forward_backward(zc, zt, tgt, 1, ehs)
+        if ops_hook_off():
+            loss, _ = tr.forward_backward_captured(zc, zt, tgt, 1, ehs)
+        else:
+            loss, _ = tr.forward_backward(zc, zt, tgt, 1, ehs)
         tr.optimizer_step(poly_lr(1e-5, st["step"], 10000), max_grad_norm=1.0)
         st["step"] += 1
         st["loss"] = loss
@@ -250,7 +264,7 @@ def secondary_measurements(pipe, blobs, args, res, dtype):
     out["configs4_ms_per_step"] = round(ms, 3)
     out["configs4_value"] = round(1e3 / ms, 3)
     out["configs4_workload"] = (f"training step, SD-2.1 UNet 865.9 M + frozen SD VAE, {res}x{res}, 7-shot, 1 episode/GPU/step: 16 sampled "
-                                "VAE encodes + UNet fwd + bwd + clip_grad_norm_ + AdamW (BASELINE.json configs[4], one GPU), eager")
+                                "VAE encodes (eager) + UNet fwd + bwd (one HIP graph) + clip_grad_norm_ + AdamW (BASELINE.json configs[4], one GPU)")
     out["configs4_loss"] = round(loss, 5)
     ab, af = agg.get("fsa_attention_bwd"), agg.get("fsa_attention")
     if ab:
@@ -263,6 +277,7 @@ def secondary_measurements(pipe, blobs, args, res, dtype):
         out["configs4_attention_fwd_frac"] = round(af[1] / af[2] / 1e12 / MFMA_PEAK_TFLOPS, 4)
     del tr
     torch.cuda.empty_cache()
+    log(f"[secondary] configs[4] done at +{time.time() - t_sec:.1f}s")
     return out
 
 
@@ -331,8 +346,13 @@ def train_main(args):
     comm_dt = torch.bfloat16 if args.grad_comm_dtype == "bf16" else torch.float32
     red = tr.make_reducer(comm_dtype=comm_dt) if world > 1 else None
 
+    use_graph = world == 1 and not args.no_graph      # fwd + bwd as one HIP graph; the overlapped all-reduce needs the eager walk
+
     def train(lat):
-        loss, _ = tr.forward_backward(lat[0], lat[1], lat[2], 1, ehs, reducer=red)  # T:1367-1391
+        if use_graph and ops_hook_off():
+            loss, _ = tr.forward_backward_captured(lat[0], lat[1], lat[2], 1, ehs)      # T:1367-1391, one graph replay
+        else:
+            loss, _ = tr.forward_backward(lat[0], lat[1], lat[2], 1, ehs, reducer=red)  # T:1367-1391
         if red is not None:
             loss = red.finish()                                                     # rank-averaged loss, streams joined
         tr.optimizer_step(poly_lr(1e-5, state["step"], 10000), max_grad_norm=1.0)  # T:1393-1395
@@ -404,7 +424,8 @@ def train_main(args):
                            "nshot": s, "resolution": res,
                            "parallelism": f"data-parallel x{world}, flat gradient all-reduce in 216 MB buckets ({args.grad_comm_dtype} on the wire) "
                                           "issued from a side stream during the backward, loss in the last bucket",
-                           "optimizer": "clip_grad_norm_(1.0) + AdamW, fp32 master", "hip_graph": False,
+                           "optimizer": "clip_grad_norm_(1.0) + AdamW, fp32 master",
+                           "hip_graph": "UNet forward + backward (UNetTrainer.forward_backward_captured)" if use_graph else False,
                            "vae_encode": "one batch of 2s+2 images per step" + (", next batch's encodes on a side stream during the UNet step" if prefetch else "")},
                 "roofline": roof, "cpu_baseline": None}
         print(json.dumps(line), flush=True)

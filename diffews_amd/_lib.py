@@ -157,6 +157,8 @@ SYMBOLS = {
     "dfw_transpose": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dfw_concat_channels": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dfw_convert_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "dfw_zero": (_i32, [_vp, _i64, _vp]),
+    "dfw_split_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "dfw_timestep_embedding": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dfw_seg_postprocess": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "dfw_seg_postprocess_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),

@@ -29,7 +29,9 @@
 
 namespace dfw {
 
-template <typename T, int BM, int BN, bool GNIN>
+// F32O: fp32 NHWC output + fp32 (or storage-dtype) residual, stored straight from the accumulators -- the fp32 residual
+// stream (see gemm_big.hip); its own instantiation, the 16-bit path's staged epilogue is unchanged.
+template <typename T, int BM, int BN, bool GNIN, bool F32O = false>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   constexpr int S = 4, RB = 64;
   constexpr int WGN = BN / 64, WGM = 8 / WGN, WTM = BM / WGM;      // wave tile WTM x 64 (128 x 64 in both configurations)
@@ -188,6 +190,46 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
+    if constexpr (F32O) {
+#pragma unroll
+      for (int i = 0; i < MB6; ++i) {
+        const int m = row_to_m(c, wm * WTM + i * 16 + l15);
+        f32x4 add[NB6];
+#pragma unroll
+        for (int j = 0; j < NB6; ++j) {            // every load of the row block before its first store
+          const int n = c.n0 + wn * 64 + j * 16 + 4 * l4;
+          f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) bb = *(const f32x4*)(p.bias + n);
+          if (p.rowbias) {
+            const f32x4 r = *(const f32x4*)(p.rowbias + (size_t)c.img * p.ldrb + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bb[e] += r[e];
+          }
+          if (p.residual) {
+            if (p.res_f32) {
+              const f32x4 r = *(const f32x4*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(float));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bb[e] += r[e];
+            } else {
+              float r[4];
+              unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bb[e] += r[e];
+            }
+          }
+          add[j] = bb;
+        }
+#pragma unroll
+        for (int j = 0; j < NB6; ++j) {
+          const int n = c.n0 + wn * 64 + j * 16 + 4 * l4;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (acc6[i][j][e] + add[j][e]) * p.out_scale;
+          *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = v;
+        }
+      }
+      return;
+    }
     float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int i = 0; i < MB6 / 2; ++i) {
@@ -423,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   }
 }
 
-template <typename T, int BM, int BN, bool GNIN>
+template <typename T, int BM, int BN, bool GNIN, bool F32O = false>
 static int launch_patch(const GemmP& p, hipStream_t st, int gn_chunks) {
   GemmP q = p;
   q.ntm = p.M / BM;
@@ -438,7 +480,7 @@ static int launch_patch(const GemmP& p, hipStream_t st, int gn_chunks) {
   int nwg = q.ntm * q.ntn;
   if (nwg > 256) nwg = 256;
   nwg = (nwg + 7) & ~7;
-  auto kfn = conv_patch_kernel<T, BM, BN, GNIN>;
+  auto kfn = conv_patch_kernel<T, BM, BN, GNIN, F32O>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), lds, st, q);
   DFW_CHECK_LAUNCH();
@@ -452,7 +494,9 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
   if (mode == 0) return false;
   if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.ups || p.splitk > 1 || p.batch > 1) return false;
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % 16) != 0 || (p.Cin % 64) != 0) return false;
-  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || p.res_f32) return false;
+  const bool f32o = p.out_mode == DFW_OUT_F32;        // fp32 residual stream: plain (no fused input GroupNorm) tiles only
+  if ((p.out_mode != DFW_OUT_T && !f32o) || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || (p.res_f32 && !f32o)) return false;
+  if (f32o && (p.gn_coef || (p.ldc % 4) != 0)) return false;
   if (p.rows_per_img != p.Ho * p.Wo || (p.gn_coef && p.Cin > 1024)) return false;
   // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  dfw_config.conv_patch = 2 also routes the
   // N % 256 == 0 layers to the 256 x 256 tile: 3 % behind gemm_big with the conflicting LDS swizzle of the first version,
@@ -469,7 +513,7 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
 
 int conv_patch_gn_chunks(const GemmP& p) {
   int bm = 0, bn = 0;
-  if (p.gn_groups <= 0 || !conv_patch_eligible(p, bm, bn) || p.N % p.gn_groups) return 0;
+  if (p.gn_groups <= 0 || p.out_mode != DFW_OUT_T || !conv_patch_eligible(p, bm, bn) || p.N % p.gn_groups) return 0;
   const int cpg = p.N / p.gn_groups;
   if (cpg < 4 || cpg > 64 || (cpg & (cpg - 1))) return 0;
   return (p.Wo / 16) * (p.Ho / (bm / 16)) * (8 / (bn / 64));
@@ -483,6 +527,10 @@ int launch_conv_patch(const GemmP& p, hipStream_t st) {
   if (p.gn_coef) {
     if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, true>(p, st, chunks) : launch_patch<_Float16, 512, 128, true>(p, st, chunks);
     return bf ? launch_patch<__bf16, 256, 256, true>(p, st, chunks) : launch_patch<_Float16, 256, 256, true>(p, st, chunks);
+  }
+  if (p.out_mode == DFW_OUT_F32) {
+    if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, false, true>(p, st, 0) : launch_patch<_Float16, 512, 128, false, true>(p, st, 0);
+    return bf ? launch_patch<__bf16, 256, 256, false, true>(p, st, 0) : launch_patch<_Float16, 256, 256, false, true>(p, st, 0);
   }
   if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, false>(p, st, chunks) : launch_patch<_Float16, 512, 128, false>(p, st, chunks);
   return bf ? launch_patch<__bf16, 256, 256, false>(p, st, chunks) : launch_patch<_Float16, 256, 256, false>(p, st, chunks);

@@ -40,7 +40,11 @@ namespace dfw {
 // on this shape (MI355X_MICROARCH 'DVFS give-back' item 7: ~1.12-1.15x); the kernels are power-limited, so
 // that is where the remaining headroom was.  Lane (l&15, l>>4) of block (i, j) owns pixel i*16 + (l&15),
 // channels j*16 + 4*(l>>4) + 0..3.
-template <typename T, int BM, int BN, int BK, int S, int OCC, bool CONV, bool PP, bool M16 = false>
+// F32O (16x16x32 ping-pong configurations only): fp32 NHWC output and an fp32 (or storage-dtype) residual -- the fp32
+// residual stream (dfw_gemm_args.residual_f32 / DFW_OUT_F32).  The accumulators are stored straight from registers
+// (a lane owns 4 consecutive channels of a pixel: 16-byte stores, four lanes per 64-byte segment); its own
+// instantiation, so the 16-bit default path's staged epilogue compiles exactly as before.
+template <typename T, int BM, int BN, int BK, int S, int OCC, bool CONV, bool PP, bool M16 = false, bool F32O = false>
 __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   // S ring stages (S-1 in flight); OCC workgroups per CU (2 * OCC waves per SIMD)
   constexpr int CH = BK / 8, RB = BK * 2;       // 16-byte chunks per row, bytes per row
@@ -399,6 +403,49 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
+      if constexpr (F32O) {
+#pragma unroll
+        for (int i = 0; i < MB6; ++i) {
+          int oy_ = 0, ox_ = 0, img_ = 0;
+          const int m = row_to_m(c, wm * WTM + i * 16 + l15, oy_, ox_, img_);
+          if (m >= p.M) continue;
+          if constexpr (!CONV) img_ = p.rowbias ? m / p.rows_per_img : 0;
+          f32x4 add[NB6];
+#pragma unroll
+          for (int j = 0; j < NB6; ++j) {          // every load of the row block before its first store
+            const int n = c.n0 + wn * 64 + j * 16 + 4 * l4;
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bb = *(const f32x4*)(p.bias + n);
+            if (p.rowbias) {
+              const f32x4 r = *(const f32x4*)(p.rowbias + (size_t)img_ * p.ldrb + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bb[e] += r[e];
+            }
+            if (p.residual) {
+              if (p.res_f32) {
+                const f32x4 r = *(const f32x4*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(float));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bb[e] += r[e];
+              } else {
+                float r[4];
+                unpack4<T>(*(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T)), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bb[e] += r[e];
+              }
+            }
+            add[j] = bb;
+          }
+#pragma unroll
+          for (int j = 0; j < NB6; ++j) {
+            const int n = c.n0 + wn * 64 + j * 16 + 4 * l4;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc6[i][j][e] + add[j][e]) * p.out_scale;
+            *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = v;
+          }
+        }
+        return;
+      }
       float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
       for (int i = 0; i < MB6 / 2; ++i) {
@@ -590,7 +637,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
   }
 }
 
-template <typename T, int BM, int BN, int BK, int S, int OCC, bool PP = false, bool M16 = false>
+template <typename T, int BM, int BN, int BK, int S, int OCC, bool PP = false, bool M16 = false, bool F32O = false>
 static int launch_big(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.ntm = (p.M + BM - 1) / BM;
@@ -609,14 +656,14 @@ static int launch_big(const GemmP& p, hipStream_t st) {
   if (nwg > 256 * OCC) nwg = 256 * OCC;
   nwg = (nwg + 7) & ~7;
   dim3 grid(nwg, zdim);
-  static bool attr_set[2] = {false, false};
+  // (the attribute is set on every launch: a host-side call of a few hundred ns, and no function-local static state)
   if (p.taps == 1) {
-    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, false, PP, M16>;
-    if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = true; }
+    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, false, PP, M16, F32O>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   } else {
-    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, true, PP, M16>;
-    if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = true; }
+    auto kfn = gemm_big_kernel<T, BM, BN, BK, S, OCC, true, PP, M16, F32O>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   }
   DFW_CHECK_LAUNCH();
@@ -642,7 +689,15 @@ static bool big_cfg_ok(const GemmP& p, const BigCfg& c) {
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
   if (!cfg().big_kernels) return false;
   if (p.splitk > 1 || (p.N % 8) != 0) return false;
-  if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.res_f32) return false;
+  const bool f32o = p.out_mode == DFW_OUT_F32;      // fp32 residual stream: the two ping-pong configurations only
+  if ((p.out_mode != DFW_OUT_T && !f32o) || p.act != DFW_ACT_NONE || (p.res_f32 && !f32o)) return false;
+  if (f32o) {
+    if (p.geglu || p.cs_n > 0 || (p.N % 128) != 0 || (p.ldc % 4) != 0) return false;
+    const BigCfg c = (p.N % 256) == 0 ? BigCfg{256, 256, 32, 1} : BigCfg{512, 128, 32, 1};
+    if (!big_cfg_ok(p, c)) return false;
+    bm = c.bm; bn = c.bn; bk = c.bk;
+    return true;
+  }
   if (cfg().big_bm) {      // sweeps: a forced configuration where it fits
     const BigCfg c = {cfg().big_bm, cfg().big_bn, cfg().big_bk, 1};
     const bool known = (c.bm == 256 && c.bn == 256 && c.bk == 32) || (c.bm == 512 && c.bn == 128 && c.bk == 32) ||
@@ -684,7 +739,7 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
 
 int gemm_big_gn_chunks(const GemmP& p) {
   int bm = 0, bn = 0, bk = 0;
-  if (p.gn_groups <= 0 || p.taps != 9 || p.geglu || !gemm_big_eligible(p, bm, bn, bk)) return 0;
+  if (p.gn_groups <= 0 || p.taps != 9 || p.geglu || p.out_mode != DFW_OUT_T || !gemm_big_eligible(p, bm, bn, bk)) return 0;
   if ((size_t)(bm + bn) * bk * 2 < 8 * 4096) return 0;            // staged epilogue needs a 32 KiB slot
   if (p.N % p.gn_groups) return 0;
   const int cpg = p.N / p.gn_groups;
@@ -699,6 +754,10 @@ int launch_gemm_big(const GemmP& p, hipStream_t st) {
   const bool bf = p.dtype_bf16 != 0;
   // 256 x 256 and 512 x 128: ping-pong schedule with v_mfma_f32_16x16x32 (A/B history in DESIGN.md section 3: +2 % each
   // against the in-phase schedule and against 32x32x16 in the same schedule; those instantiations are gone)
+  if (p.out_mode == DFW_OUT_F32) {
+    if (bm == 256) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true, true, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true, true, true>(p, st);
+    return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true, true, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true, true, true>(p, st);
+  }
   if (bm == 256 && bn == 256)
     return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true, true>(p, st);
   if (bm == 512)

@@ -391,6 +391,34 @@ __global__ __launch_bounds__(256) void convert_f32_kernel(const float* x, char* 
   }
 }
 
+// Zero fill as a KERNEL (16-byte stores): scratch and gradient-seed buffers inside captured steps must not become memset
+// nodes (a small memset node replayed next to plain launches received another launch's arguments).
+__global__ __launch_bounds__(256) void zero_kernel(i32x4* p, long long n16) {
+  const i32x4 z = {0, 0, 0, 0};
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n16; e += (long long)gridDim.x * 256) p[e] = z;
+}
+
+// fp32 -> (hi, lo) storage-dtype pair with hi = (T)x, lo = (T)(x - hi): x = hi + lo to ~2^-22 relative (fp16) -- an
+// fp32 residual-stream tensor consumed AS A GEMM OPERAND (conv_shortcut, Downsample2D / Upsample2D convs) is fed as two
+// 16-bit operands whose products are summed in the fp32 accumulator / fp32 residual epilogue, so the stream's 16-bit
+// rounding never enters the result.
+template <typename T>
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* x, char* hi, char* lo, long long n8) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n8; e += (long long)gridDim.x * 256) {
+    const f32x4 a = __builtin_nontemporal_load((const f32x4*)(x + e * 8)), b = __builtin_nontemporal_load((const f32x4*)(x + e * 8 + 4));
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    float l[8];
+    typename Tr<T>::v8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      h[i] = (T)f[i];
+      l[i] = f[i] - (float)h[i];
+    }
+    *(i32x4*)(hi + e * 8 * sizeof(T)) = as_i4<T>(h);
+    *(i32x4*)(lo + e * 8 * sizeof(T)) = pack8<T>(l);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void timestep_embedding_kernel(const float* t, T* out, int B, int dim, int flip, float shift) {
@@ -707,6 +735,30 @@ extern "C" int dfw_convert_f32(const float* x, void* y, int64_t n, int32_t dtype
   return 0;
 }
 
+extern "C" int dfw_zero(void* p, int64_t bytes, dfw_stream_t stream) {
+  if (!p || bytes <= 0) return DFW_EINVAL;
+  if ((bytes & 15) || ((uintptr_t)p & 15)) return DFW_ESHAPE;
+  const long long n16 = bytes / 16;
+  long long blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (i32x4*)p, n16);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dfw_split_f32(const float* x, void* hi, void* lo, int64_t n, int32_t dtype, dfw_stream_t stream) {
+  if (!x || !hi || !lo || n <= 0) return DFW_EINVAL;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  if (n % 8 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)lo & 15)) return DFW_ESHAPE;
+  const long long n8 = n / 8;
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((split_f32_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (char*)hi, (char*)lo, n8);
+  else hipLaunchKernelGGL((split_f32_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (char*)hi, (char*)lo, n8);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dfw_timestep_embedding(const float* timesteps, void* out, int32_t B, int32_t dim,
                                       int32_t flip_sin_to_cos, float freq_shift, int32_t dtype,
                                       dfw_stream_t stream) {
@@ -800,7 +852,7 @@ extern "C" int dfw_graph_memset_nodes(void* graph, int32_t* n_nodes) {
   return c < 0 ? DFW_EINVAL : c;
 }
 
-static const dfw_config kDefaultCfg = {1, 1, 0, 0, 0, 0, 0, 1, 1, 0};
+static const dfw_config kDefaultCfg = {1, 1, 0, 0, 0, 0, 0, 0, 1, 0};
 static dfw_config g_cfg = kDefaultCfg;
 namespace dfw { const dfw_config& cfg() { return g_cfg; } }
 

@@ -260,6 +260,48 @@ def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None,
     return out
 
 
+def zeros(shape, dtype, device="cuda"):
+    """torch.zeros whose fill is a library kernel (capture-safe: no memset node).  Sizes are padded to 16 bytes."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    esz = torch.empty(0, dtype=dtype).element_size()
+    pad = (-(n * esz)) % 16 // esz if (n * esz) % 16 else 0
+    buf = torch.empty(n + pad, dtype=dtype, device=device)
+    L.check(L.lib().dfw_zero(buf.data_ptr(), (n + pad) * esz, _stream()), "dfw_zero")
+    return buf[:n].view(*shape)
+
+
+def split_storage(x, dtype):
+    """fp32 x -> (hi, lo) in `dtype` with hi + lo = x to ~2^-22 relative (fp16): see linear_stream / conv3x3_stream."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 8 == 0
+    hi = torch.empty(x.shape, dtype=dtype, device=x.device)
+    lo = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().dfw_split_f32(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), _DT[dtype], _stream()), "dfw_split_f32")
+    return hi, lo
+
+
+def linear_stream(x, w, bias=None, residual=None):
+    """Linear whose INPUT is the residual stream (ResnetBlock2D.conv_shortcut).  16-bit stream: plain linear.  fp32 stream:
+    x is fed as two 16-bit operands (hi, lo = split_storage(x)); the second GEMM adds onto the first through the fp32 residual
+    epilogue, so the stream's 16-bit rounding never enters the fp32 result."""
+    if x.dtype != torch.float32:
+        return linear(x, w, bias=bias, residual=residual)
+    hi, lo = split_storage(x, w.dtype)
+    y = linear(hi, w, bias=bias, residual=residual, out_f32=True)
+    return linear(lo, w, residual=y, out_f32=True)
+
+
+def conv3x3_stream(x, w, cout, bias=None, **kw):
+    """conv3x3 whose INPUT is the residual stream (Downsample2D / Upsample2D convs): as linear_stream."""
+    if x.dtype != torch.float32:
+        return conv3x3(x, w, cout, bias=bias, **kw)
+    hi, lo = split_storage(x, w.dtype)
+    kw.pop("gn_groups", None)
+    y = conv3x3(hi, w, cout, bias=bias, out_f32=True, **kw)
+    return conv3x3(lo, w, cout, residual=y, out_f32=True, **kw)
+
+
 FSA_QSCALE = 64 ** -0.5 * math.log2(math.e)   # attn.scale (A:269-271, head_dim 64) in exp2 units
 
 

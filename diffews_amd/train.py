@@ -173,6 +173,7 @@ class UNetTrainer:
         self.growth_interval, self._good_steps, self.skipped_steps = int(growth_interval), 0, 0
         self._overflow_pending = None
         self._param, self._master_seen, self._pending_ref, self.reducer = None, 0, None, None
+        self._graphs = {}
         self.training = True
         self.step_count = 0
         self._derived, self._derived_version, self._derived_table = {}, -1, None
@@ -591,7 +592,7 @@ class UNetTrainer:
         a2 = ob.silu(e2)
         tape.add(a2, lambda d: tape.accum(e2, ob.silu(e2, d)))
         tproj = ops.linear(a2, P.w("tp_w"), bias=P.p("tp_b"), out_f32=True)                  # [Bt, sum Cout] fp32
-        dtproj = torch.zeros(Bt, self.tp_total, dtype=torch.float32, device=dev)            # filled by the resnets' closures
+        dtproj = ops.zeros((Bt, self.tp_total), torch.float32, dev)                         # filled by the resnets' closures
 
         def tproj_bwd(_):
             # every resnet has written its column slice of dtproj by now (they sit later on the tape)
@@ -616,7 +617,7 @@ class UNetTrainer:
         L_ctx = e.shape[1]
         ehs2d = e.reshape(Bt * L_ctx, e.shape[2]).contiguous()
         kv_all = ops.linear(ehs2d, P.w("kv_w_all"))
-        dkv_all = torch.zeros_like(kv_all)                                                   # filled by the attn2 closures
+        dkv_all = ops.zeros(kv_all.shape, kv_all.dtype, dev)                                 # filled by the attn2 closures
         tape.add(kv_all, lambda _: ob.gemm_tn(dkv_all, ehs2d, out=P.g("kv_w_all").view(1, self.kv_total, 1, ehs2d.shape[1]),
                                               accumulate=P.acc("kv_w_all"), scale=gs))
         # ---- conv_in_ref | conv_in (U:1117-1121)
@@ -674,10 +675,9 @@ class UNetTrainer:
         hn = self._gn(tape, x, "conv_norm_out.weight", "conv_norm_out.bias", self.eps, True)
         oc = cfg["out_channels"]
         pred_all = ops.conv3x3(hn, P.w("conv_out.weight")[:oc], oc, bias=P.p("conv_out.bias")[:oc], out_nchw_f32=True)
-        # gradient seeds of conv_out: support rows stay zero (pred_ref * 0, T:1381).  torch.zeros here is deliberate: the
-        # training step is not captured by the pipeline's inference graph (see _assert_no_memset_nodes there)
-        dpred = torch.zeros(Bt, h, w, 8, dtype=dt, device=dev)
-        dpn = torch.zeros(Bt, oc, h, w, dtype=torch.float32, device=dev)
+        # gradient seeds of conv_out: support rows stay zero (pred_ref * 0, T:1381); zeroed by a kernel (capture-safe)
+        dpred = ops.zeros((Bt, h, w, 8), dt, dev)
+        dpn = ops.zeros((Bt, oc, h, w), torch.float32, dev)
         return dict(tape=tape, hn=hn, pred_all=pred_all, pred=pred_all[n_ref:], n_ref=n_ref, h=h, w=w, c0=c0, oc=oc,
                     tproj=tproj, dtproj=dtproj, kv_all=kv_all, dkv_all=dkv_all, dpred=dpred, dpn=dpn)
 
@@ -720,6 +720,45 @@ class UNetTrainer:
             reducer.begin(loss)
         self._backward(c, reducer)
         return loss, c["pred"]
+
+    def forward_backward_captured(self, z_refcat, z_tag, target, timestep, ehs):
+        """forward_backward(zero_grad=True) replayed as ONE HIP graph (~2 200 kernel nodes), captured on first use per input
+        shape into static input buffers; returns the graph's (loss, pred) buffers (overwritten by the next call).  The
+        optimizer step stays outside (its step count / learning rate are host arguments), and so does an overlapped gradient
+        all-reduce: multi-GPU runs use forward_backward(reducer=...) eagerly.  Host-side bookkeeping of the step (first-touch
+        flags, derived-weight table) is identical for every step, which is what makes the capture valid."""
+        self._resolve_overflow()
+        ins = [t.to(self.device, torch.float32).contiguous() for t in (z_refcat, z_tag, target)] + [ehs.to(self.device).contiguous()]
+        key = (tuple(tuple(t.shape) for t in ins), float(timestep), self.loss_scale)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = [t.clone() for t in ins]
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):                    # lazy derived-weight copies, then the frozen batched re-layout table
+                    self.forward_backward(static[0], static[1], static[2], float(timestep), static[3])
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph(keep_graph=True)
+            dyn, self.dynamic_loss_scale = self.dynamic_loss_scale, False   # no event wait inside the capture
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    loss, pred = self.forward_backward(static[0], static[1], static[2], float(timestep), static[3])
+            finally:
+                self.dynamic_loss_scale = dyn
+            from .pipeline import _assert_no_memset_nodes
+            self.graph_nodes = _assert_no_memset_nodes(graph)
+            graph.instantiate()
+            ent = (graph, static, loss, pred)
+            self._graphs[key] = ent
+        graph, static, loss, pred = ent
+        for dst, src in zip(static, ins):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        graph.replay()
+        return loss, pred
 
     # ------------------------------------------------------------------ the reference's call surface (T:1374-1396)
     def __call__(self, *a, **k):

@@ -79,7 +79,7 @@ class _Resnet:
         h = ops.groupnorm(h, self.g2, self.b2, self.groups, self.eps, silu=True)
         sc = x
         if self.ws is not None:
-            sc = ops.linear(ops.to_storage(x, dt).view(-1, Cin), self.ws, bias=self.bs, out_f32=f32s).view(B, H, W, self.cout)
+            sc = ops.linear_stream(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
         return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups, out_f32=f32s)
 
 
@@ -195,9 +195,9 @@ class _Transformer:
         # --- GEGLU feed-forward
         ln = ops.layernorm(t, *self.ln[2], out_dtype=dt)
         ff = ops.linear(ln, self.w_ff1, bias=self.b_ff1, geglu=True)
-        # the block's output only feeds proj_out as an MFMA operand: 16-bit storage even with the fp32 stream
-        t = ops.linear(ff, self.w_ff2, bias=self.b_ff2, residual=t)
-        return ops.linear(t, self.w_out, bias=self.b_out, residual=x.view(-1, C), out_f32=f32s).view(B, H, W, C)
+        # the block's running sum is itself proj_out's operand: fp32 stream => fed as (hi, lo) (ops.linear_stream)
+        t = ops.linear(ff, self.w_ff2, bias=self.b_ff2, residual=t, out_f32=f32s)
+        return ops.linear_stream(t, self.w_out, bias=self.b_out, residual=x.view(-1, C)).view(B, H, W, C)
 
 
 class _Conv:
@@ -501,7 +501,7 @@ class MyUNet2DConditionModel:
                 skips.append(x)
             if blk["down"] is not None:
                 d = blk["down"]
-                x = ops.conv3x3(ops.to_storage(x, self.dtype), d.w, d.cout, bias=d.b, stride=2, pad=1, out_f32=self._f32s)
+                x = ops.conv3x3_stream(x, d.w, d.cout, bias=d.b, stride=2, pad=1)
                 skips.append(x)
         # ---- 4. mid (U:1189-1198)
         x = self.mid["res"][0](x, tproj)
@@ -516,7 +516,7 @@ class MyUNet2DConditionModel:
                     x = blk["attn"][j](x, ehs2d, L_ctx, n_ref)
             if blk["up"] is not None:
                 u = blk["up"]
-                x = ops.conv3x3(ops.to_storage(x, self.dtype), u.w, u.cout, bias=u.b, ups=True, out_f32=self._f32s)
+                x = ops.conv3x3_stream(x, u.w, u.cout, bias=u.b, ups=True)
         # ---- 6. out (U:1246-1249); out_scale lets the pipeline fold z0 = -v into the epilogue
         x = ops.groupnorm(x, *self.gn_out, self.groups, self.eps, silu=True, out_dtype=self.dtype)
         co = self.conv_out

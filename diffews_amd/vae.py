@@ -37,7 +37,7 @@ class _VaeResnet:
                         gn_in=(self.g1, self.b1, self.groups, 1e-6, True))
         sc = x
         if self.ws is not None:
-            sc = ops.linear(ops.to_storage(x, dt).view(-1, Cin), self.ws, bias=self.bs, out_f32=f32s).view(B, H, W, self.cout)
+            sc = ops.linear_stream(x.view(-1, Cin), self.ws, bias=self.bs).view(B, H, W, self.cout)
         return ops.conv3x3(h, self.w2, self.cout, bias=self.cb2, residual=sc, gn_groups=self.groups,
                            gn_in=(self.g2, self.b2, self.groups, 1e-6, True), out_f32=f32s)
 
@@ -110,8 +110,7 @@ class _Encoder:
             for r in res:
                 h = r(h)
             if down is not None:  # F.pad(0,1,0,1) + conv stride 2 padding 0
-                h = ops.conv3x3(ops.to_storage(h, self.dt), down.w, down.cout, bias=down.b, stride=2, pad=0,
-                                gn_groups=self.groups, out_f32=self.f32s)
+                h = ops.conv3x3_stream(h, down.w, down.cout, bias=down.b, stride=2, pad=0, gn_groups=self.groups)
         h = self.mid(h)
         h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True, out_dtype=self.dt)
         co = self.conv_out
@@ -147,8 +146,7 @@ class _Decoder:
             for r in res:
                 h = r(h)
             if up is not None:
-                h = ops.conv3x3(ops.to_storage(h, self.dt), up.w, up.cout, bias=up.b, ups=True, gn_groups=self.groups,
-                                out_f32=self.f32s)
+                h = ops.conv3x3_stream(h, up.w, up.cout, bias=up.b, ups=True, gn_groups=self.groups)
         h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True, out_dtype=self.dt)
         co = self.conv_out
         return ops.conv3x3(h, co.w, co.cout, bias=co.b, out_nchw_f32=True,

@@ -51,7 +51,8 @@ typedef struct {
   int32_t big_kernels;       /* 1 (default) gemm_big_kernel where eligible; 0: gemm_kernel tiles only */
   int32_t big_bm, big_bn, big_bk;   /* != 0: force this gemm_big configuration where it fits (sweeps), e.g. 256, 128, 64 */
   int32_t gemm_bm, gemm_bn;  /* != 0: force this gemm_kernel tile (128x128, 128x64, 64x64) instead of the cost model */
-  int32_t fsa_pipelined;     /* 1 (default) software-pipelined attention forward for pre-scaled q and > 1024 query rows */
+  int32_t fsa_pipelined;     /* 1: software-pipelined attention forward (pre-scaled q, > 1024 query rows); default 0: measured
+                              * 35 % slower than the ring kernel on MI355X in its current form */
   int32_t fsa_key_split;     /* 1 (default) split the bank readers' key range when a workspace is passed; 0 never */
   int32_t fsa_force_splits;  /* != 0: this split count for eligible launches (forward and dQ) */
 } dfw_config;
@@ -275,6 +276,15 @@ int dfw_concat_channels(const void* a, const void* b, void* y, int64_t rows, int
 /* y[i] = (storage dtype) x[i], n % 8 == 0, 16-byte aligned: the 16-bit MFMA-operand copy of an fp32 residual-stream
  * tensor where a conv / Linear consumes the stream itself (conv_shortcut, Downsample2D / Upsample2D convs). */
 int dfw_convert_f32(const float* x, void* y, int64_t n, int32_t dtype, dfw_stream_t stream);
+
+/* Zero `bytes` bytes at p (both multiples of 16) with a kernel: buffers zeroed inside a captured step (gradient seeds of
+ * the training step, T:1381: the support rows' zero gradient) must not become memset nodes -- see dfw_graph_memset_nodes. */
+int dfw_zero(void* p, int64_t bytes, dfw_stream_t stream);
+
+/* hi[i] = (storage dtype) x[i], lo[i] = (storage dtype)(x[i] - hi[i]): the two-operand form of an fp32 tensor (hi + lo = x
+ * to ~2^-22 relative in fp16).  Where the fp32 residual stream itself is a conv / Linear operand (ResnetBlock2D.conv_shortcut,
+ * Downsample2D / Upsample2D), the GEMM runs on hi, then on lo with the first result as its fp32 residual. */
+int dfw_split_f32(const float* x, void* hi, void* lo, int64_t n, int32_t dtype, dfw_stream_t stream);
 
 /* Sinusoidal timestep embedding, flip_sin_to_cos, fp32 math (diffusers Timesteps, U:1008);
  * out [B][dim] in storage dtype. */

@@ -579,3 +579,24 @@ def test_gradient_buckets_are_reduced_after_their_last_writer(hip_lib):
         assert torch.equal(snap[:n], final[s0:s0 + n])
     assert float(avg) == pytest.approx(float(loss) * 0.5)     # "sum" over one rank, times 1 / world
     assert ParamStore.TAIL >= 1
+
+
+def test_captured_training_step_equals_eager(hip_lib):
+    """forward_backward_captured: fwd + bwd replayed as one HIP graph == the eager step bit for bit (loss, pred, the whole
+    flat gradient), over optimizer steps in between (the derived weight copies are refreshed inside the graph) and with new
+    inputs per step; the capture holds no memset node."""
+    from diffews_amd.train import UNetTrainer
+    dtype = torch.bfloat16
+    ucfg, usd, _, z_refcat, z_tag, target, ehs = _train_setup(dtype, 1, 2, seed=13)
+    a = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    b = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    for step in range(3):
+        zr, zt, tg = z_refcat.cuda() * (1 + 0.1 * step), z_tag.cuda() + 0.01 * step, target.cuda()
+        la, pa = a.forward_backward(zr, zt, tg, 1, ehs.cuda())
+        lb, pb = b.forward_backward_captured(zr, zt, tg, 1, ehs.cuda())
+        assert torch.equal(la, lb) and torch.equal(pa, pb), step
+        assert torch.equal(a.P.grad, b.P.grad), step
+        a.optimizer_step(1e-4)
+        b.optimizer_step(1e-4)
+        assert torch.equal(a.P.master, b.P.master)
+    assert len(b._graphs) == 1 and b.graph_nodes > 500

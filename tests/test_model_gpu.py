@@ -400,7 +400,7 @@ def test_capture_survives_a_thread_that_allocates(models):
             i = 0
             while not stop.is_set():
                 # cold allocations of ever-changing sizes: the caching allocator cannot serve them from its pools
-                host = torch.empty(1 << 20 + (i % 3), dtype=torch.uint8).pin_memory()
+                host = torch.empty((1 << 20) + (i % 3) * 4096, dtype=torch.uint8).pin_memory()
                 with torch.cuda.stream(st):
                     dev = torch.empty((3 + i % 5) << 20, dtype=torch.uint8, device="cuda")
                     dev[:host.numel()].copy_(host, non_blocking=True)
@@ -432,18 +432,29 @@ def test_capture_survives_a_thread_that_allocates(models):
 
 def test_captured_step_rejects_memset_nodes(models):
     """DESIGN section 2 invariant: a memset node inside the pipeline-owned graph is refused at capture time
-    (regression guard for torch.zeros / zero_ / fill_ slipping into _episodes_step)."""
+    (regression guard for a hipMemsetAsync slipping into the captured step -- the library's own scratch words are zeroed
+    by kernels).  The memset node is made through the HIP runtime torch itself loaded (same stream capture)."""
     import ctypes as C
     from diffews_amd import _lib as L
     from diffews_amd.pipeline import _assert_no_memset_nodes
+    hip_path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                hip_path = line.split()[-1]
+                break
+    assert hip_path, "libamdhip64 not mapped?"
+    hip = C.CDLL(hip_path)
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipMemsetAsync.restype = C.c_int
     x = torch.empty(1 << 16, device="cuda")
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        x.zero_()                   # becomes a memset node
+        assert hip.hipMemsetAsync(C.c_void_p(x.data_ptr()), 0, 256, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
         y = x + 1
     n = C.c_int32(0)
-    assert L.lib().dfw_graph_memset_nodes(C.c_void_p(g.raw_cuda_graph()), C.byref(n)) >= 1 and n.value >= 2
+    assert L.lib().dfw_graph_memset_nodes(C.c_void_p(g.raw_cuda_graph()), C.byref(n)) == 1 and n.value >= 2
     with pytest.raises(RuntimeError, match="memset"):
         _assert_no_memset_nodes(g)
     g2 = torch.cuda.CUDAGraph(keep_graph=True)

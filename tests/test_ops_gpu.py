@@ -703,6 +703,15 @@ def test_fp32_stream_glue(ops, dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def pipelined(hip_lib):
+    """fsa_pipe_kernel is opt-in (dfw_config.fsa_pipelined): switch it on for the test, restore the defaults after."""
+    from diffews_amd import _lib
+    _lib.configure(fsa_pipelined=1)
+    yield
+    _lib.configure()
+
+
 # fsa_pipe_kernel: the software-pipelined forward (q pre-scaled, more than 1024 query rows).  Three tiles are in flight
 # per wave (S(t+2) on the matrix pipe, P(t+1) on the vector pipe, P(t).V(t) on the matrix pipe), so the cases that matter
 # are tile counts 1, 2, 3, odd / even, ragged last tiles of the own and bank segments, and the deferred rescale firing in
@@ -712,7 +721,7 @@ def test_fp32_stream_glue(ops, dtype):
                                                  (1, 1, 1100, 64, 0), (1, 2, 1100, 77, 0), (1, 1, 1100, 128, 0),
                                                  (1, 1, 1100, 192, 0), (1, 1, 1100, 200, 0), (1, 1, 1100, 320, 0),
                                                  (1, 1, 1100, 333, 0), (2, 2, 1300, 1300, 3)])
-def test_fsa_attention_pipelined_kernel(ops, dtype, B, heads, N, nkv, nshot):
+def test_fsa_attention_pipelined_kernel(ops, pipelined, dtype, B, heads, N, nkv, nshot):
     C = heads * 64
     g = torch.Generator().manual_seed(N + nkv + nshot)
     q = (torch.randn(B, N, C, generator=g)).to(dtype)
@@ -737,7 +746,7 @@ def test_fsa_attention_pipelined_kernel(ops, dtype, B, heads, N, nkv, nshot):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("step", [0.5, 2.0, 5.0, 12.0, -3.0, 40.0])
-def test_fsa_attention_pipelined_deferred_rescale_ramp(ops, dtype, step):
+def test_fsa_attention_pipelined_deferred_rescale_ramp(ops, pipelined, dtype, step):
     """The ramp of test_fsa_attention_deferred_rescale_ramp on the pipelined kernel (N = 2048: 32 tiles): 0.5 never moves
     the reference after the first tile, 2.0 every 5th tile, 5.0 every 2nd, 12.0 / 40.0 every tile (consecutive pipelined
     iterations both take the fix-up path), -3.0 falls.  Every row must match: a fix-up applied to the wrong one of O, l,
@@ -764,7 +773,7 @@ def test_fsa_attention_pipelined_deferred_rescale_ramp(ops, dtype, step):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_fsa_attention_pipelined_lockstep_equals_two_launches(ops, dtype):
+def test_fsa_attention_pipelined_lockstep_equals_two_launches(ops, pipelined, dtype):
     b, nshot, heads, N = 2, 2, 2, 1100
     C = heads * 64
     n_ref = b * nshot
@@ -778,3 +787,32 @@ def test_fsa_attention_pipelined_lockstep_equals_two_launches(ops, dtype):
                       q_prescaled=True, key_split=False)
     one = ops.fsa_attention(q, k, v, heads, k[:n_ref], v[:n_ref], nshot=nshot, n_plain=n_ref, q_prescaled=True, key_split=False)
     assert torch.equal(one, two)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stream_operand_split(ops, dtype):
+    """split_storage: hi + lo reproduces the fp32 tensor far below the storage rounding; linear_stream / conv3x3_stream on an
+    fp32 input therefore match the fp32 reference of the UNROUNDED input to accumulation precision."""
+    from diffews_amd.packing import pack_conv3x3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(512, 256, generator=g) * 3
+    hi, lo = ops.split_storage(x.cuda(), dtype)
+    assert hi.dtype == dtype and torch.equal(hi.cpu(), x.to(dtype))
+    err = rel(hi.float() + lo.float(), x)
+    assert err < (1e-6 if dtype == torch.float16 else 3e-5), err           # 2^-22 fp16, 2^-16 bf16
+    w = rnd((128, 256), dtype, 4, 256 ** -0.5)
+    bias = torch.randn(128)
+    res = torch.randn(512, 128, generator=g)
+    y = ops.linear_stream(x.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda())
+    ref = x @ w.float().t() + bias + res
+    assert y.dtype == torch.float32 and rel(y, ref) < (3e-6 if dtype == torch.float16 else 6e-5)
+    plain = ops.linear(x.to(dtype).cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out_f32=True)
+    assert rel(plain, ref) > 5 * rel(y, ref)                               # the one-operand form carries the input rounding
+    xc = torch.randn(2, 32, 32, 128, generator=g) * 2
+    wc = rnd((128, 128, 3, 3), dtype, 5, (9 * 128) ** -0.5)
+    yc = ops.conv3x3_stream(xc.cuda(), pack_conv3x3(wc).cuda(), 128, bias=bias.cuda(), stride=2, pad=0)
+    refc = F.conv2d(F.pad(xc.permute(0, 3, 1, 2), (0, 1, 0, 1)), wc.float(), bias, stride=2).permute(0, 2, 3, 1)
+    assert yc.dtype == torch.float32 and rel(yc, refc) < (3e-6 if dtype == torch.float16 else 6e-5)
+    # 16-bit stream: the plain ops
+    y16 = ops.linear_stream(x.to(dtype).cuda(), w.cuda(), bias=bias.cuda())
+    assert y16.dtype == dtype
