@@ -166,6 +166,8 @@ SYMBOLS = {
     "dfw_gemm_tn": (_i32, [C.POINTER(GemmTnArgs), _vp]),
     "dfw_gemm_tn_workspace_bytes": (_sz, [C.POINTER(GemmTnArgs)]),
     "dfw_colsum": (_i32, [_vp, _vp, _vp, _sz, _i64, _i32, _i32, _i32, _i64, _f32, _i32, _i32, _vp]),
+    "dfw_colsum_plan": (_i32, [_i64, C.POINTER(_i32), C.POINTER(_i32)]),
+    "dfw_colsum_batch": (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp]),
     "dfw_colsum_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "dfw_groupnorm_bwd": (_i32, [C.POINTER(GroupNormBwdArgs), _vp]),
     "dfw_groupnorm_bwd_workspace_bytes": (_sz, [C.POINTER(GroupNormBwdArgs)]),

@@ -441,6 +441,98 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* part, flo
   }
 }
 
+// Every column sum of a backward walk in TWO launches (dfw_colsum_batch): a device table of items, each the arguments of one
+// dfw_colsum call plus its place in the two flattened grids and its slice of the shared partial-sum workspace; a block finds
+// its item by bisection.  ~190 bias / time-projection gradients per training step were 2 x 190 launches of 6-11 us each.
+struct ColsumItem {
+  long long x, out;                 // addresses
+  long long rows_per_seg, segs, N, ldx, ldo;
+  long long scale_bits, accumulate; // float bits of the scale; accumulate flag
+  long long chunks, rpc, part_off;  // plan of the item; offset (floats) of its partial rows in the workspace
+  long long block_begin1, block_begin2;
+  long long reserved0, reserved1;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumItem* items, int n_items, float* ws) {
+  __shared__ float red[8][256];
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin1 <= blk) lo = mid; else hi = mid - 1;
+  }
+  const ColsumItem it = items[lo];
+  const int N = (int)it.N, rows_per_seg = (int)it.rows_per_seg, ldx = (int)it.ldx, rpc = (int)it.rpc, chunks = (int)it.chunks;
+  const int gx = (N + 255) / 256;
+  long long l = blk - it.block_begin1;
+  const int bx = (int)(l % gx);
+  l /= gx;
+  const int chunk = (int)(l % chunks), seg = (int)(l / chunks);
+  const char* x = (const char*)it.x;
+  float* part = ws + it.part_off;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = (bx * 32 + cl) * 8;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  if (n < N) {
+    const int r1 = min(rows_per_seg, (chunk + 1) * rpc);
+    for (int r = chunk * rpc + rl; r < r1; r += 8) {
+      float f[8];
+      unpack8<T>(*(const i32x4*)(x + (((size_t)seg * rows_per_seg + r) * ldx + n) * sizeof(T)), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cl * 8 + i] = s[i];
+  __syncthreads();
+  const int c = threadIdx.x;
+  const int nn = bx * 256 + c;
+  if (nn < N) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a += red[r][c];
+    part[((size_t)seg * chunks + chunk) * N + nn] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_batch_kernel(const ColsumItem* items, int n_items, const float* ws) {
+  __shared__ float red[16][17];
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin2 <= blk) lo = mid; else hi = mid - 1;
+  }
+  const ColsumItem it = items[lo];
+  const int N = (int)it.N, chunks = (int)it.chunks;
+  const int gx = (N + 15) / 16;
+  const long long l = blk - it.block_begin2;
+  const int bx = (int)(l % gx), seg = (int)(l / gx);
+  const float* part = ws + it.part_off;
+  const int cl = threadIdx.x & 15, l16 = threadIdx.x >> 4;
+  const int n = bx * 16 + cl;
+  float a = 0.f;
+  if (n < N)
+    for (int c = l16; c < chunks; c += 16) a += part[((size_t)seg * chunks + c) * N + n];
+  red[l16][cl] = a;
+  __syncthreads();
+  if (l16 == 0 && n < N) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = red[r][cl];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int r = 0; r < w; ++r) t[r] += t[r + w];
+    float* o = (float*)it.out + (size_t)seg * it.ldo + n;
+    const float scale = __builtin_bit_cast(float, (int)it.scale_bits);
+    *o = (it.accumulate ? *o : 0.f) + scale * t[0];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(+SiLU) backward on NHWC.  y = act(gamma * xhat + beta), xhat = (x - mean_g) * rstd_g.
 //   dz = dy * act'(z)                      dgamma[c] = sum dz * xhat      dbeta[c] = sum dz
@@ -1148,6 +1240,29 @@ extern "C" int dfw_colsum(const void* x, float* out, void* workspace, size_t wor
   DFW_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16, segs), dim3(256), 0, st, (const float*)workspace, out,
                      chunks, N, segs, (long long)(ldo > 0 ? ldo : N), scale, accumulate);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
+// HOST helper of dfw_colsum_batch: the plan of one item (chunks, rows per chunk) -- what dfw_colsum uses itself.
+extern "C" int dfw_colsum_plan(int64_t rows_per_seg, int32_t* chunks, int32_t* rpc) {
+  if (rows_per_seg <= 0 || !chunks || !rpc) return DFW_EINVAL;
+  int c, r;
+  colsum_plan((int)rows_per_seg, c, r);
+  *chunks = c; *rpc = r;
+  return 0;
+}
+
+extern "C" int dfw_colsum_batch(const void* items, int32_t n_items, int64_t total_blocks1, int64_t total_blocks2, void* workspace,
+                                int32_t dtype, dfw_stream_t stream) {
+  if (!items || !workspace || n_items <= 0 || total_blocks1 <= 0 || total_blocks2 <= 0) return DFW_EINVAL;
+  if (total_blocks1 > 0x7fffffffll || total_blocks2 > 0x7fffffffll) return DFW_ERANGE;
+  if (dtype != DFW_BF16 && dtype != DFW_F16) return DFW_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFW_BF16) hipLaunchKernelGGL((colsum_batch_kernel<__bf16>), dim3((unsigned)total_blocks1), dim3(256), 0, st, (const ColsumItem*)items, n_items, (float*)workspace);
+  else hipLaunchKernelGGL((colsum_batch_kernel<_Float16>), dim3((unsigned)total_blocks1), dim3(256), 0, st, (const ColsumItem*)items, n_items, (float*)workspace);
+  DFW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_fold_batch_kernel, dim3((unsigned)total_blocks2), dim3(256), 0, st, (const ColsumItem*)items, n_items, (const float*)workspace);
   DFW_CHECK_LAUNCH();
   return 0;
 }

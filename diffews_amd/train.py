@@ -174,6 +174,7 @@ class UNetTrainer:
         self._overflow_pending = None
         self._param, self._master_seen, self._pending_ref, self.reducer = None, 0, None, None
         self._graphs = {}
+        self._cs = ob.ColsumQueue()
         self.training = True
         self.step_count = 0
         self._derived, self._derived_version, self._derived_table = {}, -1, None
@@ -442,7 +443,7 @@ class UNetTrainer:
             N, K = P.spec[wname][1]
             ob.gemm_tn(dy, x, out=P.g(wname).view(1, N, 1, K), accumulate=P.acc(wname), scale=gs)
             if bname:
-                ob.colsum(dy, out=P.g(bname).view(1, N), accumulate=P.acc(bname), scale=gs)
+                self._cs.add(dy, P.g(bname).view(1, N), accumulate=P.acc(bname), scale=gs)
             if need_dx:
                 tape.accum(x, ops.linear(dy, self._d("T", wname)))
             if residual is not None:
@@ -461,10 +462,10 @@ class UNetTrainer:
         def bwd(dy):
             ob.gemm_tn(dy, x, taps=9, geom=(Hi, Wi, Ho, Wo, stride, 1, int(ups)), out=P.g(wname).view(1, cout, 9, Cin),
                        accumulate=P.acc(wname), scale=gs)
-            ob.colsum(dy, out=P.g(bname).view(1, cout), accumulate=P.acc(bname), scale=gs)
+            self._cs.add(dy, P.g(bname).view(1, cout), accumulate=P.acc(bname), scale=gs)
             if tslice is not None:      # d(time_emb_proj output)[img] = sum over the image's pixels (kept at loss scale)
                 o, c = tslice
-                ob.colsum(dy, segs=B, out=dtproj[:, o:o + c])
+                self._cs.add(dy, dtproj[:, o:o + c], segs=B)
             if need_dx:
                 wd = self._d("D", wname)
                 if stride == 2:
@@ -595,10 +596,11 @@ class UNetTrainer:
         dtproj = ops.zeros((Bt, self.tp_total), torch.float32, dev)                         # filled by the resnets' closures
 
         def tproj_bwd(_):
-            # every resnet has written its column slice of dtproj by now (they sit later on the tape)
+            # every resnet has queued its column slice of dtproj by now (they sit later on the tape): issue the queue
+            self._cs.flush()
             d16 = ob.nchw_to_nhwc(dtproj.view(Bt, self.tp_total, 1, 1), dt, cp=self.tp_total).view(Bt, self.tp_total)
             ob.gemm_tn(d16, a2, out=P.g("tp_w").view(1, self.tp_total, 1, a2.shape[1]), accumulate=P.acc("tp_w"), scale=gs)
-            ob.colsum(d16, out=P.g("tp_b").view(1, self.tp_total), accumulate=P.acc("tp_b"), scale=gs)
+            self._cs.add(d16, P.g("tp_b").view(1, self.tp_total), accumulate=P.acc("tp_b"), scale=gs)
             tape.accum(a2, ops.linear(d16, self._d("T", "tp_w")))
         tape.add(tproj, tproj_bwd)
         # ---- prompt K/V of all layers in one GEMM
@@ -632,14 +634,14 @@ class UNetTrainer:
             if n_ref:
                 zin = ob.nchw_to_nhwc(zr, dt, cp=8)
                 ob.gemm_tn(dx[:n_ref], zin, taps=9, geom=geom, out=P.g("conv_in_ref.weight").view(1, c0, 9, 8), accumulate=P.acc("conv_in_ref.weight"), scale=gs)
-                ob.colsum(dx[:n_ref], out=P.g("conv_in_ref.bias").view(1, c0), accumulate=P.acc("conv_in_ref.bias"), scale=gs)
+                self._cs.add(dx[:n_ref], P.g("conv_in_ref.bias").view(1, c0), accumulate=P.acc("conv_in_ref.bias"), scale=gs)
             zin = ob.nchw_to_nhwc(zq, dt, cp=8)
             g8 = ob.gemm_tn(dx[n_ref:], zin, taps=9, geom=geom, scale=gs)                  # [1, c0, 9, 8]: 4 real input channels
             if P.acc("conv_in.weight"):
                 P.g("conv_in.weight").add_(g8.view(c0, 9, 8)[..., :cfg["in_channels"]])
             else:
                 P.g("conv_in.weight").copy_(g8.view(c0, 9, 8)[..., :cfg["in_channels"]])
-            ob.colsum(dx[n_ref:], out=P.g("conv_in.bias").view(1, c0), accumulate=P.acc("conv_in.bias"), scale=gs)
+            self._cs.add(dx[n_ref:], P.g("conv_in.bias").view(1, c0), accumulate=P.acc("conv_in.bias"), scale=gs)
         tape.add(x, conv_in_bwd)
         # ---- trunk (U:1153-1243)
         lpb, nb = cfg["layers_per_block"], len(cfg["block_out_channels"])
@@ -688,10 +690,15 @@ class UNetTrainer:
         bucket's all-reduce starts as soon as its last writer is in the stream."""
         P, dt, gs = self.P, self.dtype, 1.0 / self.loss_scale
         tape, hn, h, w, c0, oc = c["tape"], c["hn"], c["h"], c["w"], c["c0"], c["oc"]
-        note = (lambda: reducer.mark(P.pop_written())) if reducer is not None else None
+        # bias / time-projection column sums are queued and issued in batches (ob.ColsumQueue): with a reducer, before every
+        # readiness report (a gradient is final only once its launch is in the stream); otherwise twice per walk
+        def _note():
+            self._cs.flush()
+            reducer.mark(P.pop_written())
+        note = _note if reducer is not None else None
         # conv_out backward: weight / bias gradients in place (padded to 8 rows), data gradient by the direct conv
         ob.gemm_tn(c["dpred"], hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=P.acc("conv_out.weight"), scale=gs)
-        ob.colsum(c["dpred"], out=P.g("conv_out.bias").view(1, 8), accumulate=P.acc("conv_out.bias"), scale=gs)
+        self._cs.add(c["dpred"], P.g("conv_out.bias").view(1, 8), accumulate=P.acc("conv_out.bias"), scale=gs)
         wdo = P.p("conv_out.weight")[:oc].view(oc, 9, c0).flip(1).permute(2, 1, 0).contiguous()     # [c0][tap'][oc] fp32
         dhn = ops.conv_small(c["dpn"], wdo, None, c0, 9, dt)
         if note:
@@ -699,6 +706,7 @@ class UNetTrainer:
         tape.accum(c["tproj"], c["dtproj"])   # seeds of the two conditioning paths: their buffers fill up during the walk
         tape.accum(c["kv_all"], c["dkv_all"])
         tape.backward(hn, dhn, after=note)
+        self._cs.flush()
         P.finish_step()
         if note:
             note()
@@ -742,6 +750,10 @@ class UNetTrainer:
             cur.wait_stream(side)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph(keep_graph=True)
+            # the batched refresh of the derived weight copies (W^T, tap-mirrored conv weights) must be PART of the graph: the
+            # optimizer rewrites the 16-bit shadow between replays.  Marking the copies stale makes the first _d() of the
+            # captured backward issue it, exactly where an eager step after an optimizer step issues it.
+            self._derived_version = -2
             dyn, self.dynamic_loss_scale = self.dynamic_loss_scale, False   # no event wait inside the capture
             try:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):

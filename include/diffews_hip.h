@@ -387,6 +387,16 @@ int dfw_colsum(const void* x, float* out, void* workspace, size_t workspace_byte
                int32_t N, int32_t ldx, int64_t ldo, float scale, int32_t accumulate, int32_t dtype, dfw_stream_t stream);
 size_t dfw_colsum_workspace_bytes(int64_t rows_per_seg, int32_t segs, int32_t N);
 
+/* Every column sum of a backward walk in two launches.  items: DEVICE array of n_items records of sixteen int64_t
+ * { x, out, rows_per_seg, segs, N, ldx, ldo, scale (float bits), accumulate, chunks, rpc, part_off, block_begin1, block_begin2,
+ *   0, 0 }: the dfw_colsum arguments of the item (x / out as addresses), its plan from dfw_colsum_plan(), the offset in floats
+ * of its segs * chunks * N partial sums in `workspace`, and its first block in the two flattened grids:
+ *   block_begin1[i+1] = block_begin1[i] + ceil(N / 256) * chunks * segs,  block_begin2[i+1] = block_begin2[i] + ceil(N / 16) * segs;
+ * total_blocks1 / 2 = the sums.  All items share `dtype`; N % 8 == 0, ldx % 8 == 0 (caller-checked).  Deterministic. */
+int dfw_colsum_plan(int64_t rows_per_seg, int32_t* chunks, int32_t* rpc);
+int dfw_colsum_batch(const void* items, int32_t n_items, int64_t total_blocks1, int64_t total_blocks2, void* workspace,
+                     int32_t dtype, dfw_stream_t stream);
+
 /* GroupNorm(+SiLU) backward (torch.nn.GroupNorm + F.silu under autograd; ResnetBlock2D.norm1/norm2,
  * Transformer2DModel.norm, conv_norm_out).  mean_rstd [B][groups][2] are the forward's statistics
  * (the tail of dfw_groupnorm's stats_ws).  dgamma / dbeta may be NULL. */

@@ -146,10 +146,10 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     (profiles/r02_stage_trace_*.txt) shows to be the floor of ANY 16-bit-storage pipeline:
     every residual-level stage adds exactly one storage rounding (2.9e-4 fp16 / 2.4e-3 bf16) and nothing else;
     measured 1.45e-3 fp16 / 1.18e-2 bf16.
-    fp16-fp32stream: residual_dtype=torch.float32 -- the residual stream summed and stored in fp32, MFMA operands fp16.
-    north_star's bar is 1e-3; measured 1.005e-3 / 0.995e-3 / 1.048e-3 at the three shapes: what remains is the fp16 rounding
-    of the conv / GEMM OPERANDS (one per branch input, profiles/r03_stage_trace_fp16_f32stream.txt), not of the stream.
-    Tolerance 1.1 x the largest measured value."""
+    fp16-fp32stream: residual_dtype=torch.float32 -- the residual stream summed and stored in fp32 and fed to the convs that
+    consume it directly (shortcuts, samplers, proj_out) as a (hi, lo) operand pair; every other MFMA operand fp16.
+    Tolerance = north_star's 1e-3; measured 7.55e-4 / 7.42e-4 / 7.72e-4 at the three shapes (what remains is the fp16 rounding
+    of the GroupNorm / LayerNorm outputs that feed the branch convs: profiles/r03_stage_trace_fp16_f32stream.txt)."""
     from diffews_amd import config, weights
     from diffews_amd.episodes import make_episode_batch
     from diffews_amd.pipeline import MarigoldPipelineRGBLatentNoise
@@ -175,7 +175,7 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
             AutoencoderKL(vcfg, vsd, torch_dtype=dt, residual_dtype=rdt),
             DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
         assert pipe.residual_dtype == (rdt or dt)
-        tol = (1.15e-3 if rdt == torch.float32 else 1.8e-3) if dt == torch.float16 else 1.5e-2
+        tol = (1.0e-3 if rdt == torch.float32 else 1.8e-3) if dt == torch.float16 else 1.5e-2
         for b, nshot, res in ((4, 1, 512), (2, 5, 512), (1, 1, 256)):
             bt = make_episode_batch(b, nshot, res, seed=40 + nshot + b, device="cuda")
             with torch.no_grad():
@@ -347,6 +347,12 @@ def test_fullsize_training_step_against_oracle_autograd(hip_lib, dt, nshot, samp
         assert r["latents"] < TRAIN_TOL["latents_bf16"], r["latents"]
 
 
-# measured on MI355X (gpurun_out/r03_train_parity.log) x 1.25 -- see DESIGN.md section 4
-TRAIN_TOL = dict(pred_bf16=3e-2, pred_fp16=6e-3, loss_bf16=5e-2, loss_fp16=1e-2, flat_bf16=0.10, flat_fp16=0.02,
-                 cos_bf16=0.995, cos_fp16=0.9998, tensor_bf16=0.5, tensor_fp16=0.2, latents_bf16=3e-2)
+# Measured on MI355X (profiles/r03_train_parity.txt), tolerance = 1.25 x the larger measured value of the dtype's cases:
+#   bf16 7-shot: pred 1.242e-2, loss 2.8e-4, flat gradient rel L2 3.79e-3, cos 0.999993, worst tensor 1.37e-2 (mid-block attn1.to_k)
+#   fp16 7-shot: pred 1.543e-3, loss 1.2e-5, flat 4.28e-4, cos 1.000000, worst tensor 5.2e-3 (up_blocks.3 attn1.to_q)
+#   bf16 2-shot, sampled VAE: latents 6.13e-3, pred 1.674e-2, loss 1.8e-4, flat 5.34e-3, cos 0.999986, worst tensor 2.09e-2
+# (the loss errors sit at fp32 summation noise: their bound is 2 x measured.)  The worst tensors are always attn1.to_q / to_k
+# of the small-gradient layers (|g| ~ 7e-3 of a flat norm ~ 1): dS = P o (dP - delta) cancels there, so the 16-bit
+# rounding of P and dS weighs most.
+TRAIN_TOL = dict(pred_bf16=2.1e-2, pred_fp16=1.95e-3, loss_bf16=6e-4, loss_fp16=3e-5, flat_bf16=6.7e-3, flat_fp16=5.4e-4,
+                 cos_bf16=0.99998, cos_fp16=0.999999, tensor_bf16=2.6e-2, tensor_fp16=6.5e-3, latents_bf16=7.7e-3)
