@@ -128,7 +128,7 @@ class AdamWArgs(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("conv_patch", _i32), ("big_kernels", _i32), ("big_bm", _i32), ("big_bn", _i32), ("big_bk", _i32),
-                ("gemm_bm", _i32), ("gemm_bn", _i32), ("fsa_pipelined", _i32), ("fsa_key_split", _i32),
+                ("gemm_bm", _i32), ("gemm_bn", _i32), ("fsa_key_split", _i32),
                 ("fsa_force_splits", _i32)]
 
 
@@ -167,6 +167,7 @@ SYMBOLS = {
     "dfw_gemm_tn_workspace_bytes": (_sz, [C.POINTER(GemmTnArgs)]),
     "dfw_colsum": (_i32, [_vp, _vp, _vp, _sz, _i64, _i32, _i32, _i32, _i64, _f32, _i32, _i32, _vp]),
     "dfw_colsum_plan": (_i32, [_i64, C.POINTER(_i32), C.POINTER(_i32)]),
+    "dfw_table_write": (_i32, [_vp, _i64, _vp, _i32, _vp]),
     "dfw_colsum_batch": (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp]),
     "dfw_colsum_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "dfw_groupnorm_bwd": (_i32, [C.POINTER(GroupNormBwdArgs), _vp]),

@@ -1244,6 +1244,23 @@ extern "C" int dfw_colsum(const void* x, float* out, void* workspace, size_t wor
   return 0;
 }
 
+// Device tables (dfw_colsum_batch, dfw_weight_relayout_batch) written through KERNEL ARGUMENTS: up to 24 records of sixteen
+// int64 travel by value in the launch, so filling a table needs neither pinned host memory nor a memcpy node -- both are
+// awkward inside a stream capture (hipHostMalloc and the host allocator's event queries are not permitted while capturing).
+struct TableChunk { long long v[24 * 16]; };
+__global__ __launch_bounds__(256) void table_write_kernel(long long* dst, const TableChunk c, int n) {
+  for (int e = threadIdx.x; e < n; e += 256) dst[e] = c.v[e];
+}
+
+extern "C" int dfw_table_write(void* table, int64_t first_record, const int64_t* records, int32_t n_records, dfw_stream_t stream) {
+  if (!table || !records || n_records <= 0 || n_records > 24 || first_record < 0) return DFW_EINVAL;
+  TableChunk c;
+  for (int i = 0; i < n_records * 16; ++i) c.v[i] = records[i];
+  hipLaunchKernelGGL(table_write_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long long*)table + first_record * 16, c, n_records * 16);
+  DFW_CHECK_LAUNCH();
+  return 0;
+}
+
 // HOST helper of dfw_colsum_batch: the plan of one item (chunks, rows per chunk) -- what dfw_colsum uses itself.
 extern "C" int dfw_colsum_plan(int64_t rows_per_seg, int32_t* chunks, int32_t* rpc) {
   if (rows_per_seg <= 0 || !chunks || !rpc) return DFW_EINVAL;

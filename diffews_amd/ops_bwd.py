@@ -85,7 +85,7 @@ class ColsumQueue:
     before it reports gradients as final to the gradient reducer, and at the end of the walk)."""
 
     def __init__(self):
-        self.items, self.keep, self.pinned = [], [], []
+        self.items, self.keep = [], []
 
     def add(self, x, out, segs=1, accumulate=False, scale=1.0):
         x2 = x.reshape(-1, x.shape[-1])
@@ -113,12 +113,13 @@ class ColsumQueue:
             b2 += ((N + 15) // 16) * segs
             off += segs * ch.value * N
         dev = self.keep[0][0].device
-        host = torch.tensor(rows, dtype=torch.int64).pin_memory()
-        table = host.to(dev, non_blocking=True)
+        table = torch.empty(len(rows), 16, dtype=torch.int64, device=dev)
+        for i0 in range(0, len(rows), 24):          # the records travel as kernel arguments (capture-safe: no pinned memory)
+            chunk = rows[i0:i0 + 24]
+            flat = (C.c_int64 * (16 * len(chunk)))(*[v for r in chunk for v in r])
+            L.check(lib.dfw_table_write(table.data_ptr(), i0, flat, len(chunk), _stream()), "dfw_table_write")
         ws = torch.empty(max(off, 1), dtype=torch.float32, device=dev)
         L.check(lib.dfw_colsum_batch(table.data_ptr(), len(rows), b1, b2, ws.data_ptr(), self.items[0][-1], _stream()), "dfw_colsum_batch")
-        if torch.cuda.is_current_stream_capturing():
-            self.pinned.append(host)        # a captured copy node reads the pinned table at every replay: keep it alive
         self.items, self.keep = [], []
 
 

@@ -51,8 +51,6 @@ typedef struct {
   int32_t big_kernels;       /* 1 (default) gemm_big_kernel where eligible; 0: gemm_kernel tiles only */
   int32_t big_bm, big_bn, big_bk;   /* != 0: force this gemm_big configuration where it fits (sweeps), e.g. 256, 128, 64 */
   int32_t gemm_bm, gemm_bn;  /* != 0: force this gemm_kernel tile (128x128, 128x64, 64x64) instead of the cost model */
-  int32_t fsa_pipelined;     /* 1: software-pipelined attention forward (pre-scaled q, > 1024 query rows); default 0: measured
-                              * 35 % slower than the ring kernel on MI355X in its current form */
   int32_t fsa_key_split;     /* 1 (default) split the bank readers' key range when a workspace is passed; 0 never */
   int32_t fsa_force_splits;  /* != 0: this split count for eligible launches (forward and dQ) */
 } dfw_config;
@@ -394,6 +392,9 @@ size_t dfw_colsum_workspace_bytes(int64_t rows_per_seg, int32_t segs, int32_t N)
  *   block_begin1[i+1] = block_begin1[i] + ceil(N / 256) * chunks * segs,  block_begin2[i+1] = block_begin2[i] + ceil(N / 16) * segs;
  * total_blocks1 / 2 = the sums.  All items share `dtype`; N % 8 == 0, ldx % 8 == 0 (caller-checked).  Deterministic. */
 int dfw_colsum_plan(int64_t rows_per_seg, int32_t* chunks, int32_t* rpc);
+/* Write n_records (<= 24) records of sixteen int64_t from HOST memory `records` into the DEVICE table at record index
+ * first_record.  The records travel as kernel arguments: no pinned memory, no memcpy node -- capture-safe. */
+int dfw_table_write(void* table, int64_t first_record, const int64_t* records, int32_t n_records, dfw_stream_t stream);
 int dfw_colsum_batch(const void* items, int32_t n_items, int64_t total_blocks1, int64_t total_blocks2, void* workspace,
                      int32_t dtype, dfw_stream_t stream);
 

@@ -87,7 +87,7 @@ def test_library_reads_nothing_from_the_environment():
             assert "getenv" not in fh.read(), f
     from diffews_amd import _lib as L
     d0 = L.configure()
-    assert d0["conv_patch"] == 1 and d0["big_kernels"] == 1 and d0["fsa_pipelined"] == 0 and d0["gemm_bm"] == 0
+    assert d0["conv_patch"] == 1 and d0["big_kernels"] == 1 and d0["fsa_key_split"] == 1 and d0["gemm_bm"] == 0
     assert L.configure(conv_patch=2, gemm_bm=128, gemm_bn=64)["conv_patch"] == 2
     with pytest.raises(RuntimeError):
         L.configure(gemm_bm=96, gemm_bn=96)
