@@ -245,6 +245,10 @@ def test_fsa_attention_backward(B, dtype, b, nshot, heads, N):
 
 
 # ------------------------------------------------------------------------------------------------ whole step
+def flat_norm_ref(gref):
+    return torch.sqrt(sum((v.double() ** 2).sum() for v in gref.values()))
+
+
 def _train_setup(dtype, b, nshot, seed=0):
     from diffews_amd import config, weights
     from oracle.unet import OracleUNet
@@ -295,9 +299,22 @@ def test_training_step_gradients_vs_oracle_autograd(hip_lib, dtype, b, nshot):
     assert set(g) == set(gref), set(gref) ^ set(g)
     # every tensor close in relative L2 (bf16 activations / activation gradients: a few % per tensor), the flat
     # gradient as a whole much closer in direction
+    # The tiny model's per-tensor band is wide because its tensors are tiny (16 x 16 latents, 32-128 channels: a bias gradient
+    # is a sum over a few hundred 16-bit-rounded values); the five worst are printed on every run so that a wrong scale on a
+    # small tensor cannot hide in the band.  At SD-2.1 size every tensor is within 2.1 % (bf16) / 0.5 % (fp16):
+    # tests/test_fullsize_gpu.py::test_fullsize_training_step_against_oracle_autograd.
     gtol = 0.12 if dtype == torch.bfloat16 else 0.03
-    worst = max(((rel(g[k], gref[k]), k) for k in gref), key=lambda t: t[0])
-    assert worst[0] < gtol, worst
+    ranked = sorted(((rel(g[k], gref[k]), k, float(gref[k].norm())) for k in gref), reverse=True)
+    for e, k, n in ranked[:5]:
+        print(f"[tiny-train-parity] {str(dtype):15s} b={b} {nshot}-shot worst tensor {k:64s} rel L2 {e:.3e} |g_ref| {n:.3e}")
+    worst = ranked[0]
+    assert worst[0] < gtol, worst[:2]
+    # no tensor with a non-negligible gradient may be off by a SCALE factor: compare norms, not only directions
+    for k in gref:
+        nr = float(gref[k].norm())
+        if nr > 1e-3 * float(flat_norm_ref(gref)):
+            ratio = float(g[k].float().norm().cpu()) / nr
+            assert abs(ratio - 1.0) < (0.06 if dtype == torch.bfloat16 else 0.015), (k, ratio)
     flat = torch.cat([g[k].float().cpu().reshape(-1) for k in sorted(gref)])
     flat_ref = torch.cat([gref[k].reshape(-1) for k in sorted(gref)])
     cos = float(F.cosine_similarity(flat, flat_ref, dim=0))
