@@ -14,6 +14,22 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+_SD_CACHE = {}
+
+
+def _sd(kind, round_to=None):
+    """Seeded synthetic SD-2.1 UNet / SD VAE weights (diffusers layout), generated once per (model, rounding) for the whole
+    module: 12-15 s of host time each, and eight call sites below.  The dicts are read-only for every consumer."""
+    from diffews_amd import config, weights
+    key = (kind, round_to)
+    if key not in _SD_CACHE:
+        if kind == "unet":
+            _SD_CACHE[key] = weights.synthetic_unet_state_dict(config.get("sd21_unet"), round_to=round_to)
+        else:
+            _SD_CACHE[key] = weights.synthetic_vae_state_dict(config.get("sd_vae"), round_to=round_to)
+    return _SD_CACHE[key]
+
+
 @pytest.fixture(scope="module")
 def sd21(hip_lib):
     from diffews_amd import config, weights
@@ -23,8 +39,8 @@ def sd21(hip_lib):
     from diffews_amd.vae import AutoencoderKL
     dt = torch.bfloat16
     ucfg, vcfg = config.get("sd21_unet"), config.get("sd_vae")
-    unet = MyUNet2DConditionModel(ucfg, weights.synthetic_unet_state_dict(ucfg), torch_dtype=dt)
-    vae = AutoencoderKL(vcfg, weights.synthetic_vae_state_dict(vcfg), torch_dtype=dt)
+    unet = MyUNet2DConditionModel(ucfg, _sd("unet"), torch_dtype=dt)
+    vae = AutoencoderKL(vcfg, _sd("vae"), torch_dtype=dt)
     kw = {k: v for k, v in config.get("scheduler").items() if not k.startswith("_")}
     pipe = MarigoldPipelineRGBLatentNoise(unet, vae, DDIMSchedulerCustomized(**kw),
                                           text_embeds=weights.synthetic_text_embed(ucfg).cuda())
@@ -161,8 +177,8 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     from oracle.vae import OracleVAE
     ucfg, vcfg = config.get("sd21_unet"), config.get("sd_vae")
     kwf = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
-    usd = weights.synthetic_unet_state_dict(ucfg, round_to=dt)
-    vsd = weights.synthetic_vae_state_dict(vcfg, round_to=dt)
+    usd = _sd("unet", dt)
+    vsd = _sd("vae", dt)
     te = weights.synthetic_text_embed(ucfg).to(dt).float()
     prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
     torch.backends.cudnn.allow_tf32 = False
@@ -215,8 +231,8 @@ def test_fullsize_other_resolutions_against_oracle_on_device(hip_lib):
     dt = torch.float16
     ucfg, vcfg = config.get("sd21_unet"), config.get("sd_vae")
     kwf = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
-    usd = weights.synthetic_unet_state_dict(ucfg, round_to=dt)
-    vsd = weights.synthetic_vae_state_dict(vcfg, round_to=dt)
+    usd = _sd("unet", dt)
+    vsd = _sd("vae", dt)
     te = weights.synthetic_text_embed(ucfg).to(dt).float()
     prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
     torch.backends.cudnn.allow_tf32 = False
@@ -254,7 +270,7 @@ def _fullsize_train_case(dt, nshot, res, sample_vae, seed):
     from oracle.vae import OracleVAE
     ucfg, vcfg = config.get("sd21_unet"), config.get("sd_vae")
     kwf = lambda c: {k: v for k, v in c.items() if not k.startswith("_")}
-    usd = weights.synthetic_unet_state_dict(ucfg, round_to=dt)
+    usd = _sd("unet", dt)
     g = torch.Generator().manual_seed(seed)
     ehs = torch.randn(1, 77, ucfg["cross_attention_dim"], generator=g).to(dt).float().cuda()      # 77-token prompt (T:1368)
     h = res // 8
@@ -262,7 +278,7 @@ def _fullsize_train_case(dt, nshot, res, sample_vae, seed):
     if sample_vae:
         # the frozen VAE's SAMPLED encodes (T:1347-1358): engine moments + noise from a device generator vs the oracle's
         # moments + the same noise (same seed, shape, device, dtype => the same stream)
-        vsd = weights.synthetic_vae_state_dict(vcfg, round_to=dt)
+        vsd = _sd("vae", dt)
         bt = make_episode_batch(1, nshot, res, seed=seed, device="cuda")
         qmask = (bt["query_mask"].float()[:, None].repeat(1, 3, 1, 1) * 2 - 1).contiguous()
         srcs = [torch.cat([bt["support_imgs"], bt["query_img"]]).contiguous(), bt["support_masks"], qmask]
