@@ -49,7 +49,16 @@ struct FsaBwdP {
   // [(batch - n_plain) * nsplit][n][heads * 64]; fsa_dq_combine_kernel sums them in order.  dQ is linear in the keys.
   int nsplit;
   float* part;
+  // row constants as the kernels read them: stat[0 .. total) = -delta, stat[total .. 2 total) = -lse (total = batch * heads * n),
+  // written by fsa_delta_kernel into the caller's `delta` scratch (2 * total floats)
+  const float* stat; long long stat_half; uint32_t stat_bytes;
 };
+
+// A 256-thread kernel is allowed 512 registers per wave, and with that budget hipcc 7.2 puts MFMA accumulators in AGPRs and
+// copies them to VGPRs and back around the vector work: 256 v_accvgpr_read / _write per tile beside 32 MFMAs in the dK/dV
+// kernel (SQ_INSTS_VALU 353 per wave-tile, the kernels were vector-issue-bound on copies).  Asking for two waves per SIMD
+// caps the budget at 256, every MFMA takes the VGPR form and the copies disappear.
+#define DFW_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2)))
 
 __device__ __forceinline__ uint32_t row_off(int row, int chunk) {   // K-style image: b128 row reads
   return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
@@ -58,10 +67,11 @@ __device__ __forceinline__ uint32_t tr_off(int row, int dcol) {     // V-style i
   return (uint32_t)(row * 128 + ((((dcol >> 3) ^ (((row >> 1) & 1) << 2))) << 4) + ((dcol & 7) << 1));
 }
 
-// delta[b][h][q] = sum_d dO * O   (fp32)
+// stat[e] = -delta[b][h][q] = -sum_d dO * O,  stat[total + e] = -lse[b][h][q]   (fp32): the two row constants in the form
+// the dQ / dK-dV kernels start their accumulators from (the dK-dV kernel fetches them by LDS-DMA: no arithmetic on the way)
 template <typename T>
-__global__ __launch_bounds__(256) void fsa_delta_kernel(const char* o, const char* dout, float* delta, int batch, int heads,
-                                                        int n, int ldo, long long obs, int ldd, long long dbs) {
+__global__ __launch_bounds__(256) void fsa_delta_kernel(const char* o, const char* dout, const float* lse, float* delta, int batch,
+                                                        int heads, int n, int ldo, long long obs, int ldd, long long dbs) {
   const long long total = (long long)batch * heads * n;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int qi = (int)(e % n);
@@ -78,13 +88,14 @@ __global__ __launch_bounds__(256) void fsa_delta_kernel(const char* o, const cha
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc += a[i] * d[i];
     }
-    delta[e] = acc;
+    delta[e] = -acc;
+    delta[total + e] = -lse[e];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <typename T>
-__global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
+__global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dq_kernel(const FsaBwdP p) {
   constexpr int KT = 64, TILE = KT * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];   // [buf][K rows | K tr | V rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,7 +110,6 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int bank_b = b - p.n_plain;
   const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);
-  const __amdgpu_buffer_rsrc_t rkv = make_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.dout, p.do_bytes);
   const uint32_t voff = p.voff;
 
@@ -116,10 +126,9 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
     }
   }
   const size_t stat = ((size_t)b * p.heads + head) * p.n + (qok ? qrow : 0);
-  const float nlse = qok ? -p.lse[stat] : -INFINITY;     // invalid rows: P = exp2(s + (-inf)) = 0... (see below)
-  const float ndelta = qok ? -p.delta[stat] : 0.f;
+  const float nlse = qok ? -p.lse[stat] : 0.f;           // rows past the end: Q = dO = 0, P = exp2(0) = 1, dP = dS = 0
+  const float ndelta = qok ? p.stat[stat] : 0.f;
 
-  const int srow0 = tid >> 3, sc = tid & 7;
   const int tiles_own = (p.n_kv + KT - 1) / KT;
   const int tiles_bank = (p.nshot > 0 && bank_b >= 0) ? tiles_own : 0;
   const int ntiles = tiles_own + (tiles_bank ? p.nshot * tiles_bank : 0);
@@ -129,26 +138,29 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
   const int seg0 = parted ? split * nseg / p.nsplit : 0, seg1 = parted ? (split + 1) * nseg / p.nsplit : nseg;
   const int t_begin = seg0 == 0 ? 0 : tiles_own + (seg0 - 1) * tiles_bank;
   const int t_end = parted ? tiles_own + (seg1 - 1) * tiles_bank : ntiles;
-  i32x4 gk[2], gv[2];
-  auto issue = [&](int t) {
+  // Key-side tiles by LDS-DMA into the double buffer, as in the dK/dV kernel below: per 64-key tile three 8 KiB images
+  // [K rows | K tr | V rows], wave w issues pieces w and w + 4 of each (6 instructions), swizzles applied on the source side.
+  const u32x4 rkd = make_srd(p.k, p.kv_bytes);
+  const uint32_t lds0 = lds_addr(smem);
+  auto issue = [&](int t, int buf) {
     int img = b, tt = t;
     if (t >= tiles_own) { img = bank_b * p.nshot + (t - tiles_own) / tiles_bank; tt = (t - tiles_own) % tiles_bank; }
-    const size_t base = (size_t)img * p.kvbs + head * 64 + sc * 8;
+    const uint32_t dst = lds0 + (uint32_t)buf * (3 * TILE);
+    int lane_i = lane;                       // lane-derived indices behind an opaque copy: never hoisted and spilled across the loop
+    asm volatile("" : "+v"(lane_i));
+    const int lrow = lane_i >> 3, slot = lane_i & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = tt * KT + srow0 + 32 * i;
-      const uint32_t o = key < p.n_kv ? (uint32_t)((base + (size_t)key * p.ldkv) * sizeof(T)) : kOOB;
-      gk[i] = buf_load16(rkv, o);
-      gv[i] = buf_load16(rkv, o == kOOB ? kOOB : o + voff);
-    }
-  };
-  auto write_lds = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow0 + 32 * i;
-      *(i32x4*)(buf + row_off(row, sc)) = gk[i];
-      *(i32x4*)(buf + TILE + tr_off(row, sc * 8)) = gk[i];
-      *(i32x4*)(buf + 2 * TILE + row_off(row, sc)) = gv[i];
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave + 4 * j) * 8 + lrow;
+      const int key = tt * KT + row;
+      const bool ok = key < p.n_kv;
+      const int cr = slot ^ ((row >> 1) & 7);                    // row image: chunk of LDS slot `slot`
+      const int ct = slot ^ (((row >> 1) & 1) << 2);             // transposed-read image
+      const size_t kb = (size_t)img * p.kvbs + (size_t)key * p.ldkv + head * 64;
+      const uint32_t piece = (uint32_t)(wave + 4 * j) * 1024u;
+      dma16(rkd, ok ? (uint32_t)((kb + cr * 8) * sizeof(T)) : kOOB, dst + piece);
+      dma16(rkd, ok ? (uint32_t)((kb + ct * 8) * sizeof(T)) : kOOB, dst + TILE + piece);
+      dma16(rkd, ok ? (uint32_t)((kb + cr * 8) * sizeof(T)) + voff : kOOB, dst + 2 * TILE + piece);
     }
   };
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -158,13 +170,16 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 
-  issue(t_begin);
-  write_lds(smem);
-  __syncthreads();
+  // the Q / dO fragments and the row constants came by compiler-visible loads: one full wait the compiler understands, so that
+  // it plants no vmcnt of its own inside the loop (which would drain the DMA of the next tile)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  issue(t_begin, 0);
   int cur = 0;
   for (int t = t_begin; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    if (more) issue(t + 1);
+    wait_vm<0>();                      // this wave's pieces of tile t have landed
+    __builtin_amdgcn_s_barrier();      // tile t visible to every wave; every wave is done reading tile t-1
+    asm volatile("" ::: "memory");
+    if (t + 1 < t_end) issue(t + 1, cur ^ 1);
     const char* kbuf = smem + cur * 3 * TILE;
     const char* ktr = kbuf + TILE;
     const char* vbuf = kbuf + 2 * TILE;
@@ -176,8 +191,7 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[kb][r] = qok ? nlse : 0.f; dp[kb][r] = ndelta; }
-    DFW_BWD_PRIO(1);           // the MFMA chains outrank the other waves' softmax VALU (forward: +9 %)
+      for (int r = 0; r < 16; ++r) { s[kb][r] = nlse; dp[kb][r] = ndelta; }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -189,18 +203,23 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
         dp[kb] = Tr<T>::mfma(vf, dof[ss], dp[kb]);
       }
     }
-    DFW_BWD_PRIO(0);
-    // dS^T = P^T o dP^T ; rows of S^T are keys: (r & 3) + 8 (r >> 2) + 4 lh within the 32-key block
+    // dS^T = P^T o dP^T ; rows of S^T are keys: (r & 3) + 8 (r >> 2) + 4 lh within the 32-key block.
+    // No per-element mask in the full tiles (it was 68 of the loop's ~190 vector instructions): a query row past the end has
+    // Q = dO = 0 and constants 0, so P = 1 and dS = 0; keys past the end exist only in an image's last tile, where their
+    // scores are sent to -inf under a wave-uniform branch (their K rows are zero anyway, this keeps P finite).
+    if (nvalid < KT) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= nvalid) s[kb][r] = -INFINITY;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float pr = (qok && key < nvalid) ? __builtin_amdgcn_exp2f(s[kb][r]) : 0.f;
-        s[kb][r] = pr * dp[kb][r];
-      }
-    // dQ^T += K^T dS^T
-    DFW_BWD_PRIO(1);
+      for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]) * dp[kb][r];
+    // dQ^T += K^T dS^T   (no s_setprio fences between the stages: the compiler interleaves block 1's exponentials with block
+    // 0's MFMAs, which the fences prevented)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -220,9 +239,6 @@ __global__ __launch_bounds__(256) void fsa_bwd_dq_kernel(const FsaBwdP p) {
           o[d] = Tr<T>::mfma(kf, pf, o[d]);
         }
       }
-    DFW_BWD_PRIO(0);
-    if (more) write_lds(smem + (cur ^ 1) * 3 * TILE);
-    __syncthreads();
     cur ^= 1;
   }
   if (qok && parted) {
@@ -273,19 +289,32 @@ __global__ __launch_bounds__(256) void fsa_dq_combine_kernel(const FsaBwdP p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+// Round 3: the query-side tiles arrive by LDS-DMA (buffer_load ... lds) into a double buffer -- no register staging, no
+// ds_write phase, ONE barrier per tile (the register-staged single buffer needed two and held 16 + 1 staging registers):
+// per 64-row tile four 8 KiB images [Q rows | Q tr | dO rows | dO tr] (Q and dO are fetched twice, once per swizzle: the row
+// image serves the b128 row reads of S / dP, the transposed image the ds_read_b64_tr_b16 of dV^T / dK^T; the second fetch is
+// an L2 hit) and the two row constants (-lse, -delta: 2 x 256 B, dword LDS-DMA from the negated copies fsa_delta_kernel
+// wrote).  Wave w issues pieces w and w + 4 of every image (8 instructions), wave 0 the constants too.  Schedule of tile t:
+// vmcnt(0) (tile t was issued a whole tile ago) -> barrier (publishes tile t; every wave is done with tile t-1, whose buffer
+// is free) -> issue tile t+1 into the other buffer -> the MFMA / softmax work of tile t.  The loop contains no compiler-visible
+// vector-memory operation, so nothing but the explicit vmcnt(0) ever waits on the DMA.  Rows past the end of the image are
+// zero-filled by the bounds check (Q = dO = 0, constants 0): P = 1, dP = dS = 0, and both products receive exact zeros.
+__device__ __forceinline__ void dma4(u32x4 srd, uint32_t voff, uint32_t lds_byte) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(voff), "s"(srd) : "memory");
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
-  constexpr int QT = 64, TILE = QT * 128;
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [Q rows | Q tr | dO rows | dO tr] (32 KiB, single buffer)
-  __shared__ float stats[2][QT];                                  // [-lse | -delta][q]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const FsaBwdP p) {
+  constexpr int QT = 64, TILE = QT * 128, BUF = 4 * TILE + 2 * QT * 4;   // four images + [-lse | -delta]
+  extern __shared__ __attribute__((aligned(16))) char smem[];            // 2 * BUF = 65 KiB (dynamic: above the static limit)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, kimg = blockIdx.z;
   const int key = blockIdx.x * 128 + wave * 32 + lr;      // the key this lane owns (column of S)
   const bool kok = key < p.n_kv;
-  const __amdgpu_buffer_rsrc_t rqkv = make_rsrc(p.q, p.qkv_bytes);
   const __amdgpu_buffer_rsrc_t rkv = make_rsrc(p.k, p.kv_bytes);
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.dout, p.do_bytes);
   const uint32_t voff = p.voff;
   // B operands: lane holds K[key][16 s + 8 lh + 0..7] (= K^T[k = d][col = key]), same for V
   typename Tr<T>::v8 kf[4], vf[4];
@@ -303,36 +332,36 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
   const int tiles_q = (p.n + QT - 1) / QT;
   const int ntiles = nsrc * tiles_q;
 
-  const int srow0 = tid >> 3, sc = tid & 7;
-  i32x4 gq[2], gd[2];
-  float gst = 0.f;
+  const u32x4 rq = make_srd(p.q, p.qkv_bytes), rdo = make_srd(p.dout, p.do_bytes), rst = make_srd(p.stat, p.stat_bytes);
+  const uint32_t lds0 = lds_addr(smem);
   auto issue = [&](int t) {
     const int img = t < tiles_q ? kimg : src1, tt = t < tiles_q ? t : t - tiles_q;
+    const uint32_t dst = lds0 + (uint32_t)(t & 1) * BUF;
+    int lane_i = lane;                       // lane-derived indices behind an opaque copy: never hoisted and spilled across the loop
+    asm volatile("" : "+v"(lane_i));
+    const int lrow = lane_i >> 3, slot = lane_i & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int qi = tt * QT + srow0 + 32 * i;
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave + 4 * j) * 8 + lrow;
+      const int qi = tt * QT + row;
       const bool ok = qi < p.n;
-      gq[i] = buf_load16(rqkv, ok ? (uint32_t)(((size_t)img * p.bs + (size_t)qi * p.ld + head * 64 + sc * 8) * sizeof(T)) : kOOB);
-      gd[i] = buf_load16(rdo, ok ? (uint32_t)(((size_t)img * p.obs + (size_t)qi * p.ldo + head * 64 + sc * 8) * sizeof(T)) : kOOB);
+      const int cr = slot ^ ((row >> 1) & 7);                    // row image: chunk of LDS slot `slot`
+      const int ct = slot ^ (((row >> 1) & 1) << 2);             // transposed-read image
+      const size_t qb = (size_t)img * p.bs + (size_t)qi * p.ld + head * 64;
+      const size_t db = (size_t)img * p.obs + (size_t)qi * p.ldo + head * 64;
+      const uint32_t piece = (uint32_t)(wave + 4 * j) * 1024u;
+      dma16(rq, ok ? (uint32_t)((qb + cr * 8) * sizeof(T)) : kOOB, dst + piece);
+      dma16(rq, ok ? (uint32_t)((qb + ct * 8) * sizeof(T)) : kOOB, dst + TILE + piece);
+      dma16(rdo, ok ? (uint32_t)((db + cr * 8) * sizeof(T)) : kOOB, dst + 2 * TILE + piece);
+      dma16(rdo, ok ? (uint32_t)((db + ct * 8) * sizeof(T)) : kOOB, dst + 3 * TILE + piece);
     }
-    if (tid < 2 * QT) {       // threads 0..63: -lse, 64..127: -delta of the tile's rows
-      const int qi = tt * QT + (tid & 63);
+    if (wave == 0) {                         // [-lse | -delta] of the tile's 64 rows: one dword per lane each
+      const int qi = tt * QT + lane_i;
+      const bool ok = qi < p.n;
       const size_t st = ((size_t)img * p.heads + head) * p.n + qi;
-      if (qi < p.n) gst = tid < QT ? -p.lse[st] : -p.delta[st];
-      else gst = tid < QT ? -INFINITY : 0.f;        // rows past the end: P = exp2(-inf) = 0
+      dma4(rst, ok ? (uint32_t)((p.stat_half + st) * sizeof(float)) : kOOB, dst + 4 * TILE);
+      dma4(rst, ok ? (uint32_t)(st * sizeof(float)) : kOOB, dst + 4 * TILE + QT * 4);
     }
-  };
-  auto write_lds = [&]() {
-    char* base = smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow0 + 32 * i;
-      *(i32x4*)(base + row_off(row, sc)) = gq[i];
-      *(i32x4*)(base + TILE + tr_off(row, sc * 8)) = gq[i];
-      *(i32x4*)(base + 2 * TILE + row_off(row, sc)) = gd[i];
-      *(i32x4*)(base + 3 * TILE + tr_off(row, sc * 8)) = gd[i];
-    }
-    if (tid < 2 * QT) stats[tid >> 6][tid & 63] = gst;
   };
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   f32x16 dk[2], dv[2];     // dK^T / dV^T [d block][rows d, col = key]
@@ -341,45 +370,56 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
 
+  // The K / V fragments were fetched with compiler-visible buffer loads: without a wait the COMPILER understands it cannot
+  // prove them complete across the loop back-edge and plants vmcnt(1) / vmcnt(0) in front of the tile's MFMAs -- which would
+  // also drain the DMA of tile t+1 issued just before (seen in the first build's ISA).  One full wait here removes them.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   issue(0);
-  write_lds();
-  __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) issue(t + 1);          // next tile's global loads fly during this tile's MFMAs
-    const char* qrow_t = smem;
+    wait_vm<0>();                      // this wave's pieces of tile t have landed
+    __builtin_amdgcn_s_barrier();      // tile t visible to every wave; every wave is done reading tile t-1
+    asm volatile("" ::: "memory");
+    if (t + 1 < ntiles) issue(t + 1);  // flies during this tile's MFMAs
+    const char* qrow_t = smem + (t & 1) * BUF;
     const char* qtr = qrow_t + TILE;
     const char* drow = qrow_t + 2 * TILE;
     const char* dtr = qrow_t + 3 * TILE;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      // S = Q K^T - lse ; dP = dO V^T - delta   (rows = queries: (r & 3) + 8 (r >> 2) + 4 lh of the 32-row block)
-      f32x16 s, dp;
+    const float* stats = (const float*)(qrow_t + 4 * TILE);      // [0..63] -lse, [64..127] -delta
+    // One tile = two 32-row query blocks qb, three stages each: A(qb) S = Q K^T - lse and dP = dO V^T - delta (8 MFMAs),
+    // B(qb) P = exp2(S), dS = P o dP, 16-bit pack (48 vector instructions), C(qb) dV^T += dO^T P and dK^T += Q^T dS (8 MFMAs).
+    // Written as A(0) | A(1) + B(0) | C(0) + B(1) | C(1) in ONE scheduling region, with sched_group_barrier pipelines that put
+    // the vector work of one block into the MFMA gaps of the other: a wave that runs the stages back to back leaves the matrix
+    // pipe idle during B and the vector pipe idle during A / C, and with two waves per SIMD the partner covers only part of it
+    // (counters before: MFMA busy 40 %, 34 % of wave time parked on waits).
+    f32x16 sa[2], da2[2];
+    typename Tr<T>::v8 pf[2][2], sf[2][2];     // [qb][k-step]: P and dS as B operands
+    auto stage_a = [&](int qb) {
+      // rows = queries: (r & 3) + 8 (r >> 2) + 4 lh of the 32-row block
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        s[r] = stats[0][qi];
-        dp[r] = stats[1][qi];
+        sa[qb][r] = stats[qi];
+        da2[qb][r] = stats[QT + qi];
       }
-      DFW_BWD_PRIO(1);
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
         const int row = qb * 32 + lr;
         const typename Tr<T>::v8 qa = as_v8<T>(*(const i32x4*)(qrow_t + row_off(row, 2 * ss + lh)));
         const typename Tr<T>::v8 da = as_v8<T>(*(const i32x4*)(drow + row_off(row, 2 * ss + lh)));
-        s = Tr<T>::mfma(qa, kf[ss], s);
-        dp = Tr<T>::mfma(da, vf[ss], dp);
+        sa[qb] = Tr<T>::mfma(qa, kf[ss], sa[qb]);
+        da2[qb] = Tr<T>::mfma(da, vf[ss], da2[qb]);
       }
-      DFW_BWD_PRIO(0);
-      typename Tr<T>::v8 pf[2], sf[2];       // P and dS as B operands: k-step t2 <- registers 8 t2 .. 8 t2 + 7
+    };
+    auto stage_b = [&](int qb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pr = kok ? __builtin_amdgcn_exp2f(s[r]) : 0.f;
-        pf[r >> 3][r & 7] = (T)pr;
-        sf[r >> 3][r & 7] = (T)(pr * dp[r]);
+        const float pr = __builtin_amdgcn_exp2f(sa[qb][r]);     // a key past the end: K = V = 0 (bounds check), P finite, its column is never stored
+        pf[qb][r >> 3][r & 7] = (T)pr;
+        sf[qb][r >> 3][r & 7] = (T)(pr * da2[qb][r]);
       }
-      // dV^T += dO^T P ; dK^T += Q^T dS   (A fragments: transposed reads, rows in the accumulator's k order)
-      DFW_BWD_PRIO(1);
+    };
+    auto stage_c = [&](int qb) {
+      // A fragments: transposed reads, rows in the accumulator's k order
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const int row0 = qb * 32 + 16 * t2 + 4 * lh + tq, row1 = row0 + 8;
@@ -391,15 +431,17 @@ __global__ __launch_bounds__(256) void fsa_bwd_dkv_kernel(const FsaBwdP p) {
           typename Tr<T>::v8 da, qa;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { da[j] = dlo[j]; da[4 + j] = dhi[j]; qa[j] = qlo[j]; qa[4 + j] = qhi[j]; }
-          dv[d] = Tr<T>::mfma(da, pf[t2], dv[d]);
-          dk[d] = Tr<T>::mfma(qa, sf[t2], dk[d]);
+          dv[d] = Tr<T>::mfma(da, pf[qb][t2], dv[d]);
+          dk[d] = Tr<T>::mfma(qa, sf[qb][t2], dk[d]);
         }
       }
-      DFW_BWD_PRIO(0);
-    }
-    __syncthreads();                  // every wave is done reading this tile
-    if (more) write_lds();
-    __syncthreads();
+    };
+    stage_a(0);
+    stage_a(1);
+    stage_b(0);
+    stage_c(0);
+    stage_b(1);
+    stage_c(1);
   }
   if (kok) {
     // D layout of dK^T / dV^T: col = key (this lane), rows d = (r & 3) + 8 (r >> 2) + 4 lh of the 32-d block
@@ -642,6 +684,19 @@ extern "C" int dfw_silu(const void* a, const void* dy, void* y, int64_t n, int32
   return 0;
 }
 
+static void launch_dkv(bool bf, dim3 grid, hipStream_t st, const dfw::FsaBwdP& p) {
+  constexpr int kLds = 2 * (4 * 64 * 128 + 2 * 64 * 4);
+  if (bf) {
+    auto kfn = dfw::fsa_bwd_dkv_kernel<__bf16>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), kLds, st, p);
+  } else {
+    auto kfn = dfw::fsa_bwd_dkv_kernel<_Float16>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), kLds, st, p);
+  }
+}
+
 // Same rule as the forward's fsa_split_count (attention.hip), for the dQ grid: 128-row workgroups, up to 3 per CU.
 static int fsa_bwd_split_count(const dfw_fsa_bwd_args* a) {
   if (!cfg().fsa_key_split || a->nshot < 2) return 1;
@@ -681,13 +736,16 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
     const long long total = (long long)a->batch * a->heads * a->n;
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
-    if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
-    else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
+    if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
+    else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
     DFW_CHECK_LAUNCH();
   }
   FsaBwdP p;
   p.q = (const char*)a->qkv; p.k = p.q + (size_t)C * es; p.v = p.q + (size_t)2 * C * es;
   p.dout = (const char*)a->dout; p.lse = a->lse; p.delta = a->delta;
+  p.stat = a->delta; p.stat_half = (long long)a->batch * a->heads * a->n;
+  if (p.stat_half * 8 >= (1ll << 31)) return DFW_ERANGE;
+  p.stat_bytes = (uint32_t)(p.stat_half * 8);
   p.dq = (char*)a->dqkv; p.dk = p.dq + (size_t)C * es; p.dv = p.dq + (size_t)2 * C * es;
   p.qkv_bytes = (uint32_t)(qe * es); p.do_bytes = (uint32_t)(oe * es); p.dqkv_bytes = (uint32_t)(de * es);
   p.batch = a->batch; p.heads = a->heads; p.n = a->n; p.nshot = a->nshot; p.n_plain = a->n_plain;
@@ -716,8 +774,7 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
     else hipLaunchKernelGGL((fsa_dq_combine_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
   }
-  if (bf) hipLaunchKernelGGL((fsa_bwd_dkv_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((fsa_bwd_dkv_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  launch_dkv(bf, grid, st, p);
   DFW_CHECK_LAUNCH();
   return 0;
 }
@@ -745,13 +802,16 @@ extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream
     const long long total = (long long)a->batch * a->heads * a->n_q;
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
-    if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
-    else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
+    if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
+    else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
     DFW_CHECK_LAUNCH();
   }
   FsaBwdP p;
   p.q = (const char*)a->q; p.k = kc; p.v = vc;
   p.dout = (const char*)a->dout; p.lse = a->lse; p.delta = a->delta;
+  p.stat = a->delta; p.stat_half = (long long)a->batch * a->heads * a->n_q;
+  if (p.stat_half * 8 >= (1ll << 31)) return DFW_ERANGE;
+  p.stat_bytes = (uint32_t)(p.stat_half * 8);
   p.dq = (char*)a->dq; p.dk = (char*)a->dk; p.dv = (char*)a->dv;
   p.qkv_bytes = (uint32_t)(qe * es); p.do_bytes = (uint32_t)(oe * es); p.dqkv_bytes = 0;
   p.batch = a->batch; p.heads = a->heads; p.n = a->n_q; p.nshot = 0; p.n_plain = a->batch;
@@ -765,8 +825,7 @@ extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream
   if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), gq, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), gq, dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
-  if (bf) hipLaunchKernelGGL((fsa_bwd_dkv_kernel<__bf16>), gk, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((fsa_bwd_dkv_kernel<_Float16>), gk, dim3(256), 0, st, p);
+  launch_dkv(bf, gk, st, p);
   DFW_CHECK_LAUNCH();
   return 0;
 }

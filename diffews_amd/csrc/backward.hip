@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t tn_off(int row, int ch) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_kernel(const TnP p) {
   constexpr int TILE = 64 * 256;   // bytes of one [64][128] tile
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [buf][A|B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnP p) {
 //   * CONV: the im2col gather keeps (image, oy, ox) of each of the lane's rows and advances them by 32 rows per stage with
 //     predicated wraps (Wo >= 8 and Ho * Wo >= 32, checked on the host) -- no division, no divergent branch in the loop.
 template <typename T, int NSA, int NSB, bool CONV>
-__global__ __launch_bounds__(256 * NSA * NSB) void gemm_tn_ring_kernel(const TnP p) {
+__global__ __launch_bounds__(256 * NSA * NSB) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_ring_kernel(const TnP p) {
   constexpr int BKR = 32, S = 4, SUB = BKR * 256, NSUB = NSA + NSB, STAGE = NSUB * SUB;
   constexpr int NW = 4 * NSA * NSB, DPS = NSUB * 8 / NW;
   static_assert(NSUB * 8 % NW == 0, "DMA instructions divide evenly over the waves");

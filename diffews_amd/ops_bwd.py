@@ -246,7 +246,7 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     assert C3 == 3 * Cq and qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
     assert out.shape == (B, N, Cq) and dout.shape == out.shape and lse.shape == (B, heads, N) and lse.dtype == torch.float32
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(2, B, heads, N, dtype=torch.float32, device=qkv.device)   # (-delta | -lse), see the header
     a = L.FsaBwdArgs()
     a.qkv, a.out, a.dout, a.lse, a.delta, a.dqkv = qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr()
     a.batch, a.heads, a.n, a.nshot, a.n_plain = B, heads, N, nshot, n_plain
@@ -285,7 +285,7 @@ def attention_bwd(q, k, v, out, dout, lse, heads, dk_out, dv_out, scale=None):
     assert dk_out.shape == (B, Lc, Cq) and dv_out.shape == dk_out.shape and dk_out.stride(2) == 1
     assert dk_out.stride(0) == dv_out.stride(0) and dk_out.stride(1) == dv_out.stride(1)
     dq = torch.empty(B, N, Cq, dtype=q.dtype, device=q.device)
-    delta = torch.empty(B, heads, N, dtype=torch.float32, device=q.device)
+    delta = torch.empty(2, B, heads, N, dtype=torch.float32, device=q.device)
     a = L.AttnBwdArgs()
     a.q, a.k, a.v, a.out, a.dout, a.lse, a.delta = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
     a.dq, a.dk, a.dv = dq.data_ptr(), dk_out.data_ptr(), dv_out.data_ptr()

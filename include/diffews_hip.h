@@ -464,8 +464,9 @@ int dfw_convert_to_f32(const void* x, float* y, int64_t n, float scale, int32_t 
 
 /* KV-fusion attention backward for the lock-step batch (dfw_fsa_args.n_plain form; nshot == 0: plain
  * self-attention).  qkv [batch][n][ld >= 3C]: the fused projection output with q PRE-SCALED
- * (dfw_gemm_args.colscale); out / dout [batch][n][ldo]; lse from the forward; delta [batch][heads][n] is
- * scratch.  dqkv [batch][n][ldd >= 3C] receives (dq, dk, dv) with dq taken with respect to the UNSCALED
+ * (dfw_gemm_args.colscale); out / dout [batch][n][ldo]; lse from the forward; delta is scratch of
+ * 2 * batch * heads * n floats (the kernels keep -rowsum(dO o O) in the first half and -lse in the second so the dK/dV
+ * kernel fetches both row constants of a query tile with one LDS-DMA descriptor).  dqkv [batch][n][ldd >= 3C] receives (dq, dk, dv) with dq taken with respect to the UNSCALED
  * projection output, so it is the dY of the QKV Linear as is.  scale = attn.scale (A:269-271). */
 typedef struct {
   const void* qkv; const void* out; const void* dout; const float* lse; float* delta; void* dqkv;
@@ -484,7 +485,7 @@ size_t dfw_fsa_attention_bwd_workspace_bytes(const dfw_fsa_bwd_args* a);
 /* The same backward with queries and keys / values in their own tensors (attn2 of the training step, T:1368-1375, on
  * the MFMA path: forward = dfw_fsa_attention with n_kv = 77 prompt tokens and lse requested).  q [batch][n_q][heads*64]
  * PRE-SCALED as above; k / v [batch][n_kv][heads*64] column slices of ONE buffer (v >= k, same strides); out / dout share
- * strides; lse / delta fp32 [batch][heads][n_q] (delta is scratch).  dq with respect to the unscaled projection output;
+ * strides; lse fp32 [batch][heads][n_q]; delta: scratch of 2 * batch * heads * n_q floats, as above.  dq with respect to the unscaled projection output;
  * dk / dv share strides.  Strides in elements.  Deterministic: no cross-workgroup sums. */
 typedef struct {
   const void* q; const void* k; const void* v; const void* out; const void* dout; const float* lse; float* delta;
