@@ -117,7 +117,7 @@ class AttnBwdArgs(C.Structure):
                 ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32),
                 ("ldq", _i32), ("ldkv", _i32), ("ldo", _i32), ("lddq", _i32), ("lddkv", _i32),
                 ("q_bs", _i64), ("kv_bs", _i64), ("o_bs", _i64), ("dq_bs", _i64), ("dkv_bs", _i64),
-                ("scale", _f32), ("dtype", _i32)]
+                ("scale", _f32), ("dtype", _i32), ("workspace", _vp), ("workspace_bytes", _sz)]
 
 
 class AdamWArgs(C.Structure):
@@ -183,6 +183,7 @@ SYMBOLS = {
     "dfw_fsa_attention_bwd": (_i32, [C.POINTER(FsaBwdArgs), _vp]),
     "dfw_fsa_attention_bwd_workspace_bytes": (_sz, [C.POINTER(FsaBwdArgs)]),
     "dfw_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
+    "dfw_attention_bwd_workspace_bytes": (_sz, [C.POINTER(AttnBwdArgs)]),
     "dfw_cross_attention_bwd": (_i32, [C.POINTER(XattnBwdArgs), _vp]),
     "dfw_cross_attention_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dfw_silu": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),

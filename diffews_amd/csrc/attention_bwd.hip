@@ -52,6 +52,11 @@ struct FsaBwdP {
   // row constants as the kernels read them: stat[0 .. total) = -delta, stat[total .. 2 total) = -lse (total = batch * heads * n),
   // written by fsa_delta_kernel into the caller's `delta` scratch (2 * total floats)
   const float* stat; long long stat_half; uint32_t stat_bytes;
+  // dK/dV query split (short key axis: the 77 prompt tokens are ONE key block per image and head, 40 workgroups on the 64x64
+  // level): grid.x lists every key block qsplit times, instance c walks the c-th run of the query tiles and leaves fp32
+  // partials in kvpart [2 (dK | dV)][qsplit][batch][n_kv][heads * 64]; fsa_dkv_fold_kernel sums them in order.
+  int qsplit;
+  float* kvpart;
 };
 
 // A 256-thread kernel is allowed 512 registers per wave, and with that budget hipcc 7.2 puts MFMA accumulators in AGPRs and
@@ -72,24 +77,30 @@ __device__ __forceinline__ uint32_t tr_off(int row, int dcol) {     // V-style i
 template <typename T>
 __global__ __launch_bounds__(256) void fsa_delta_kernel(const char* o, const char* dout, const float* lse, float* delta, int batch,
                                                         int heads, int n, int ldo, long long obs, int ldd, long long dbs) {
+  // 8 adjacent lanes per row, 16 bytes each: a wave-instruction reads 8 whole 128-byte rows (one thread per row made it
+  // touch 64 different cache lines per load: 18 us where the bytes take 8)
   const long long total = (long long)batch * heads * n;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int qi = (int)(e % n);
-    const long long bh = e / n;
-    const int h = (int)(bh % heads), b = (int)(bh / heads);
-    const char* po = o + ((size_t)b * obs + (size_t)qi * ldo + h * 64) * sizeof(T);
-    const char* pd = dout + ((size_t)b * dbs + (size_t)qi * ldd + h * 64) * sizeof(T);
+  const int c = threadIdx.x & 7;
+  for (long long e0 = (long long)blockIdx.x * 32; e0 < total; e0 += (long long)gridDim.x * 32) {
+    const long long e = e0 + (threadIdx.x >> 3);
     float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    if (e < total) {
+      const int qi = (int)(e % n);
+      const long long bh = e / n;
+      const int h = (int)(bh % heads), b = (int)(bh / heads);
       float a[8], d[8];
-      unpack8<T>(*(const i32x4*)(po + c * 16), a);
-      unpack8<T>(*(const i32x4*)(pd + c * 16), d);
+      unpack8<T>(*(const i32x4*)(o + ((size_t)b * obs + (size_t)qi * ldo + h * 64) * sizeof(T) + c * 16), a);
+      unpack8<T>(*(const i32x4*)(dout + ((size_t)b * dbs + (size_t)qi * ldd + h * 64) * sizeof(T) + c * 16), d);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc += a[i] * d[i];
     }
-    delta[e] = -acc;
-    delta[total + e] = -lse[e];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (c == 0 && e < total) {
+      delta[e] = -acc;
+      delta[total + e] = -lse[e];
+    }
   }
 }
 
@@ -312,7 +323,8 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, kimg = blockIdx.z;
-  const int key = blockIdx.x * 128 + wave * 32 + lr;      // the key this lane owns (column of S)
+  const int kblk = (int)blockIdx.x / p.qsplit, qchunk = (int)blockIdx.x - kblk * p.qsplit;
+  const int key = kblk * 128 + wave * 32 + lr;            // the key this lane owns (column of S)
   const bool kok = key < p.n_kv;
   const __amdgpu_buffer_rsrc_t rkv = make_rsrc(p.k, p.kv_bytes);
   const uint32_t voff = p.voff;
@@ -330,7 +342,8 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
   const int nsrc = (p.nshot > 0 && kimg < p.n_plain) ? 2 : 1;
   const int src1 = p.nshot > 0 ? p.n_plain + kimg / p.nshot : 0;
   const int tiles_q = (p.n + QT - 1) / QT;
-  const int ntiles = nsrc * tiles_q;
+  const int ntiles_all = nsrc * tiles_q;
+  const int t_begin = (int)((long long)qchunk * ntiles_all / p.qsplit), ntiles = (int)((long long)(qchunk + 1) * ntiles_all / p.qsplit);
 
   const u32x4 rq = make_srd(p.q, p.qkv_bytes), rdo = make_srd(p.dout, p.do_bytes), rst = make_srd(p.stat, p.stat_bytes);
   const uint32_t lds0 = lds_addr(smem);
@@ -374,8 +387,8 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
   // prove them complete across the loop back-edge and plants vmcnt(1) / vmcnt(0) in front of the tile's MFMAs -- which would
   // also drain the DMA of tile t+1 issued just before (seen in the first build's ISA).  One full wait here removes them.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-  issue(0);
-  for (int t = 0; t < ntiles; ++t) {
+  if (t_begin < ntiles) issue(t_begin);
+  for (int t = t_begin; t < ntiles; ++t) {
     wait_vm<0>();                      // this wave's pieces of tile t have landed
     __builtin_amdgcn_s_barrier();      // tile t visible to every wave; every wave is done reading tile t-1
     asm volatile("" ::: "memory");
@@ -387,10 +400,13 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
     const float* stats = (const float*)(qrow_t + 4 * TILE);      // [0..63] -lse, [64..127] -delta
     // One tile = two 32-row query blocks qb, three stages each: A(qb) S = Q K^T - lse and dP = dO V^T - delta (8 MFMAs),
     // B(qb) P = exp2(S), dS = P o dP, 16-bit pack (48 vector instructions), C(qb) dV^T += dO^T P and dK^T += Q^T dS (8 MFMAs).
-    // Written as A(0) | A(1) + B(0) | C(0) + B(1) | C(1) in ONE scheduling region, with sched_group_barrier pipelines that put
+    // Written as A(0) A(1) B(0) C(0) B(1) C(1) in ONE scheduling region without s_setprio fences, so that the compiler puts
     // the vector work of one block into the MFMA gaps of the other: a wave that runs the stages back to back leaves the matrix
     // pipe idle during B and the vector pipe idle during A / C, and with two waves per SIMD the partner covers only part of it
-    // (counters before: MFMA busy 40 %, 34 % of wave time parked on waits).
+    // (counters before: MFMA busy 40 %, 34 % of wave time parked on waits; 1403 -> 1287 us on the 64x64-level 7-shot launch.
+    // An explicit sched_group_barrier pipeline of the same stages was 3.5 % slower than the compiler's own interleave; an
+    // 8-wave workgroup whose two wave groups split the query rows -- equal tile counts for support and query images -- was
+    // 3-8 % slower on every level: the shared barrier costs more than the balance gains).
     f32x16 sa[2], da2[2];
     typename Tr<T>::v8 pf[2][2], sf[2][2];     // [qb][k-step]: P and dS as B operands
     auto stage_a = [&](int qb) {
@@ -443,7 +459,21 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
     stage_b(1);
     stage_c(1);
   }
-  if (kok) {
+  if (kok && p.qsplit > 1) {
+    const size_t Cc = (size_t)p.heads * 64, slab = (size_t)p.qsplit * p.batch * p.n_kv * Cc;
+    float* pk = p.kvpart + (((size_t)qchunk * p.batch + kimg) * p.n_kv + key) * Cc + head * 64;
+    const float ln2 = 0.6931471805599453f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = dk[d][4 * g + e] * ln2; c[e] = dv[d][4 * g + e]; }
+        *(f32x4*)(pk + d * 32 + 8 * g + 4 * lh) = a;
+        *(f32x4*)(pk + slab + d * 32 + 8 * g + 4 * lh) = c;
+      }
+  } else if (kok) {
     // D layout of dK^T / dV^T: col = key (this lane), rows d = (r & 3) + 8 (r >> 2) + 4 lh of the 32-d block
     char* kb = p.dk + ((size_t)kimg * p.dkvbs + (size_t)key * p.lddkv + head * 64) * sizeof(T);
     char* vb = p.dv + ((size_t)kimg * p.dkvbs + (size_t)key * p.lddkv + head * 64) * sizeof(T);
@@ -458,6 +488,30 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
         *(i32x2*)(kb + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(a);
         *(i32x2*)(vb + (d * 32 + 8 * g + 4 * lh) * sizeof(T)) = pack4<T>(c);
       }
+  }
+}
+
+// dk / dv [img][key][c] = sum over the query chunks (in order) of the fp32 partials; one thread per 4 columns
+template <typename T>
+__global__ __launch_bounds__(256) void fsa_dkv_fold_kernel(const FsaBwdP p) {
+  const int Cc = p.heads * 64, c4n = Cc / 4;
+  const long long total = (long long)p.batch * p.n_kv * c4n;
+  const size_t slab = (size_t)p.qsplit * p.batch * p.n_kv * Cc, chunk = (size_t)p.batch * p.n_kv * Cc;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c4 = (int)(e % c4n);
+    const long long rk = e / c4n;
+    const int key = (int)(rk % p.n_kv), img = (int)(rk / p.n_kv);
+    const float* src = p.kvpart + ((size_t)img * p.n_kv + key) * Cc + c4 * 4;
+    f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + slab);
+    for (int q = 1; q < p.qsplit; ++q) {
+      const f32x4 a2 = *(const f32x4*)(src + q * chunk), c2 = *(const f32x4*)(src + slab + q * chunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] += a2[i]; c[i] += c2[i]; }
+    }
+    float av[4] = {a[0], a[1], a[2], a[3]}, cv[4] = {c[0], c[1], c[2], c[3]};
+    const size_t o = ((size_t)img * p.dkvbs + (size_t)key * p.lddkv + c4 * 4) * sizeof(T);
+    *(i32x2*)(p.dk + o) = pack4<T>(av);
+    *(i32x2*)(p.dv + o) = pack4<T>(cv);
   }
 }
 
@@ -734,8 +788,8 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
   // delta = rowsum(dO o O)
   {
     const long long total = (long long)a->batch * a->heads * a->n;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
+    int g = (int)((total + 31) / 32);
+    if (g > 8192) g = 8192;
     if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
     else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n, a->ldo, (long long)a->n * a->ldo, a->ldo, (long long)a->n * a->ldo);
     DFW_CHECK_LAUNCH();
@@ -754,7 +808,7 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
   p.scale = a->scale;
   p.n_kv = a->n; p.ldkv = a->ld; p.lddkv = a->ldd; p.kvbs = p.bs; p.dkvbs = p.dbs;
   p.kv_bytes = p.qkv_bytes - (uint32_t)(C * es); p.voff = (uint32_t)(C * es);
-  p.nsplit = 1; p.part = nullptr;
+  p.nsplit = 1; p.part = nullptr; p.qsplit = 1; p.kvpart = nullptr;
   {
     const int ns = fsa_bwd_split_count(a);
     if (ns > 1 && a->workspace && a->workspace_bytes >= dfw_fsa_attention_bwd_workspace_bytes(a) && (((uintptr_t)a->workspace) & 15) == 0) {
@@ -779,6 +833,24 @@ extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t str
   return 0;
 }
 
+// Query split of the dK/dV kernel for a short key axis: as many instances per key block as it takes to put about two
+// workgroups on every CU, each walking at least two query tiles.  1 when the launch fills the chip by itself.
+static int attn_bwd_qsplit(const dfw_attn_bwd_args* a) {
+  const long long blocks = (long long)((a->n_kv + 127) / 128) * a->heads * a->batch;
+  const int tiles = (a->n_q + 63) / 64;
+  if (blocks >= 256 || tiles < 4) return 1;
+  long long qs = (512 + blocks - 1) / blocks;
+  if (qs > tiles / 2) qs = tiles / 2;
+  return qs < 1 ? 1 : (int)qs;
+}
+
+extern "C" size_t dfw_attention_bwd_workspace_bytes(const dfw_attn_bwd_args* a) {
+  if (!a || a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kv <= 0) return 0;
+  const int qs = attn_bwd_qsplit(a);
+  if (qs <= 1) return 0;
+  return (size_t)2 * qs * a->batch * a->n_kv * a->heads * 64 * sizeof(float);
+}
+
 // General form: queries and keys / values in their own tensors (attn2 of the training step on the MFMA path: the 77 prompt
 // tokens are two 64-key tiles, the ragged one masked).  Same kernels, same conventions (q pre-scaled, lse from the forward).
 extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream) {
@@ -800,8 +872,8 @@ extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream
   const bool bf = a->dtype == DFW_BF16;
   {
     const long long total = (long long)a->batch * a->heads * a->n_q;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
+    int g = (int)((total + 31) / 32);
+    if (g > 8192) g = 8192;
     if (bf) hipLaunchKernelGGL((fsa_delta_kernel<__bf16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
     else hipLaunchKernelGGL((fsa_delta_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const char*)a->out, (const char*)a->dout, a->lse, a->delta, a->batch, a->heads, a->n_q, a->ldo, (long long)a->o_bs, a->ldo, (long long)a->o_bs);
     DFW_CHECK_LAUNCH();
@@ -820,12 +892,27 @@ extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream
   p.scale = a->scale;
   p.n_kv = a->n_kv; p.ldkv = a->ldkv; p.lddkv = a->lddkv; p.kvbs = a->kv_bs; p.dkvbs = a->dkv_bs;
   p.kv_bytes = (uint32_t)(ke * es); p.voff = (uint32_t)(vc - kc);
-  p.nsplit = 1; p.part = nullptr;
-  dim3 gq((a->n_q + 127) / 128, a->heads, a->batch), gk((a->n_kv + 127) / 128, a->heads, a->batch);
+  p.nsplit = 1; p.part = nullptr; p.qsplit = 1; p.kvpart = nullptr;
+  {
+    const int qs = attn_bwd_qsplit(a);
+    if (qs > 1 && a->workspace && a->workspace_bytes >= dfw_attention_bwd_workspace_bytes(a) && (((uintptr_t)a->workspace) & 15) == 0) {
+      p.qsplit = qs;
+      p.kvpart = (float*)a->workspace;
+    }
+  }
+  dim3 gq((a->n_q + 127) / 128, a->heads, a->batch), gk((a->n_kv + 127) / 128 * p.qsplit, a->heads, a->batch);
   if (bf) hipLaunchKernelGGL((fsa_bwd_dq_kernel<__bf16>), gq, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fsa_bwd_dq_kernel<_Float16>), gq, dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
   launch_dkv(bf, gk, st, p);
   DFW_CHECK_LAUNCH();
+  if (p.qsplit > 1) {
+    const long long total = (long long)a->batch * a->n_kv * (C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (bf) hipLaunchKernelGGL((fsa_dkv_fold_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fsa_dkv_fold_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, p);
+    DFW_CHECK_LAUNCH();
+  }
   return 0;
 }

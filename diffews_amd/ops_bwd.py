@@ -271,7 +271,7 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     return dqkv
 
 
-def attention_bwd(q, k, v, out, dout, lse, heads, dk_out, dv_out, scale=None):
+def attention_bwd(q, k, v, out, dout, lse, heads, dk_out, dv_out, scale=None, q_split=True):
     """Flash backward with queries and keys / values in their own tensors (attn2 on the MFMA path).  q [B, N, heads*64]
     PRE-SCALED (linear(..., colscale=(C, FSA_QSCALE))); k / v [B, L, heads*64] column slices of one buffer; out / dout
     [B, N, heads*64] contiguous; lse [B, heads, N] from fsa_attention(..., lse=); dk_out / dv_out: views that receive
@@ -294,6 +294,10 @@ def attention_bwd(q, k, v, out, dout, lse, heads, dk_out, dv_out, scale=None):
     a.q_bs, a.kv_bs, a.o_bs, a.dq_bs, a.dkv_bs = q.stride(0), k.stride(0), N * Cq, N * Cq, dk_out.stride(0)
     a.scale = scale if scale is not None else 64 ** -0.5
     a.dtype = _dt(q)
+    nbytes = L.lib().dfw_attention_bwd_workspace_bytes(C.byref(a)) if q_split else 0
+    if nbytes:      # short key axis: query split of the dK/dV kernel
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     L.check(L.lib().dfw_attention_bwd(C.byref(a), _stream()), "dfw_attention_bwd")
     return dq
 

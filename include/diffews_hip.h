@@ -495,9 +495,14 @@ typedef struct {
   int64_t q_bs, kv_bs, o_bs, dq_bs, dkv_bs;
   float scale;
   int32_t dtype;
+  /* Optional scratch of dfw_attention_bwd_workspace_bytes() (16-byte aligned; 0 bytes when the launch fills the chip by
+   * itself): with a short key axis (77 prompt tokens = one key block per image and head) the dK/dV kernel then splits the
+   * query rows over several workgroups per key block (fp32 partials, summed in order: still deterministic). */
+  void* workspace; size_t workspace_bytes;
 } dfw_attn_bwd_args;
 
 int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream);
+size_t dfw_attention_bwd_workspace_bytes(const dfw_attn_bwd_args* a);
 
 /* Cross-attention (attn2) backward over a short context; same tensor conventions as dfw_cross_attention.
  * dq [batch][n_q][heads*64] (strides lddq / dq_bs); dk / dv [batch][L][heads*64] at row stride lddkv, image stride

@@ -384,6 +384,12 @@ def test_attention_backward_separate_kv(B, dtype, Bn, heads, N, Lc):
     assert rel(dkv[..., :C], kvr.grad[..., :C]) < 2 * TOL[dtype], "dk"
     assert rel(dkv[..., C:2 * C], kvr.grad[..., C:2 * C]) < 2 * TOL[dtype], "dv"
     assert float(dkv[..., 2 * C:].abs().sum()) == 0
+    # the dK/dV query split (short key axis, dfw_attn_bwd_args.workspace): same numbers up to the fp32 summation order of
+    # the chunks, and bit-identical from run to run (chunks are folded in order, no atomics)
+    dkv1, dkv2 = torch.zeros_like(kvg), torch.zeros_like(kvg)
+    ob.attention_bwd(qg, kvg[..., :C], kvg[..., C:2 * C], out, dout.cuda(), lse, heads, dkv1[..., :C], dkv1[..., C:2 * C], q_split=False)
+    ob.attention_bwd(qg, kvg[..., :C], kvg[..., C:2 * C], out, dout.cuda(), lse, heads, dkv2[..., :C], dkv2[..., C:2 * C])
+    assert torch.equal(dkv2, dkv) and rel(dkv1, dkv) < 0.5 * TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
