@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("stride", _i32), ("pad", _i32), ("ups", _i32), ("rows_per_img", _i32),
                 ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),
                 ("batch", _i32), ("strideA", _i64), ("strideW", _i64), ("strideC", _i64), ("dtype", _i32),
-                ("gn_partial", _vp), ("gn_groups", _i32), ("gn_in_coef", _vp), ("gn_in_silu", _i32),
+                ("gn_partial", _vp), ("gn_groups", _i32),
                 ("colscale", _f32), ("colscale_n", _i32), ("residual_f32", _i32)]
 
 
@@ -48,7 +48,7 @@ class XattnArgs(C.Structure):
 class GroupNormArgs(C.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("stats_ws", _vp), ("stats_ws_bytes", _sz),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("ldx", _i32), ("ldy", _i32),
-                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pre_partial", _vp), ("pre_chunks", _i32), ("coef_out", _vp),
+                ("eps", _f32), ("silu", _i32), ("dtype", _i32), ("pre_partial", _vp), ("pre_chunks", _i32),
                 ("x_f32", _i32)]
 
 
@@ -129,7 +129,7 @@ class AdamWArgs(C.Structure):
 class Config(C.Structure):
     _fields_ = [("conv_patch", _i32), ("big_kernels", _i32), ("big_bm", _i32), ("big_bn", _i32), ("big_bk", _i32),
                 ("gemm_bm", _i32), ("gemm_bn", _i32), ("fsa_key_split", _i32),
-                ("fsa_force_splits", _i32)]
+                ("fsa_force_splits", _i32), ("big_min_tiles", _i32)]
 
 
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)
@@ -143,7 +143,6 @@ SYMBOLS = {
     "dfw_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
     "dfw_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _sz]),
     "dfw_gemm_gn_chunks": (_i32, [C.POINTER(GemmArgs)]),
-    "dfw_gemm_gn_input_ok": (_i32, [C.POINTER(GemmArgs)]),
     "dfw_fsa_attention": (_i32, [C.POINTER(FsaArgs), _vp]),
     "dfw_fsa_workspace_bytes": (_sz, [C.POINTER(FsaArgs)]),
     "dfw_cross_attention": (_i32, [C.POINTER(XattnArgs), _vp]),

@@ -31,7 +31,7 @@ namespace dfw {
 
 // F32O: fp32 NHWC output + fp32 (or storage-dtype) residual, stored straight from the accumulators -- the fp32 residual
 // stream (see gemm_big.hip); its own instantiation, the 16-bit path's staged epilogue is unchanged.
-template <typename T, int BM, int BN, bool GNIN, bool F32O = false>
+template <typename T, int BM, int BN, bool F32O = false>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   constexpr int S = 4, RB = 64;
   constexpr int WGN = BN / 64, WGM = 8 / WGN, WTM = BM / WGM;      // wave tile WTM x 64 (128 x 64 in both configurations)
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   // patch source offsets are recomputed at every issue (once per chunk: ~10 VALU per instruction) rather than kept in
   // PPW registers through the K loop
   int pl_img = 0, pl_oy0 = 0, pl_ox0 = 0;
-  uint32_t tr_mask = 0;                              // GNIN: bit i = this lane's pixel of transform item i lies inside the image
   auto patch_off = [&](int i) __attribute__((always_inline)) -> uint32_t {
     const int q = 16 * (wave + 8 * i) + (lane >> 2);
     const int qy = q / PW, qx = q - qy * PW;
@@ -95,16 +94,6 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   };
   auto setup_patch = [&](const TileC& c) {
     pl_img = c.img; pl_oy0 = c.oy0; pl_ox0 = c.ox0;
-    if constexpr (GNIN) {
-      tr_mask = 0;
-#pragma unroll
-      for (int i = 0; i < PPW; ++i) {
-        const int q = ((wave >> 2) + 2 * i) * 64 + lane;
-        const int qy = q / PW, qx = q - qy * PW;
-        const int iy = c.oy0 - 1 + qy, ix = c.ox0 - 1 + qx;
-        if (q < PPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) tr_mask |= 1u << i;
-      }
-    }
   };
   uint32_t w_off[SW];
   auto setup_w = [&](const TileC& c) {
@@ -324,76 +313,6 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
     }
   };
 
-  // ---- GNIN: in-place GroupNorm(+SiLU) of a landed patch, once per element (the nine taps read the result).
-  // Work item = 64 consecutive patch pixels x one 8-channel group (one ds_read_b128 / ds_write_b128 per lane; 16 consecutive
-  // pixels hit 16 distinct slots of a bank row, as for the fragment reads).  Wave w takes items w, w + 8, ...: group w & 3
-  // for all of them, so its 8 (scale, shift) pairs are wave-uniform and live in 16 SGPRs (one s_load pair per chunk from
-  // gn_coef[img][cin][2]; scalar loads sit outside the vmcnt ring).  Out-of-image pixels keep the DMA's zeros: the conv pads
-  // the NORMALISED input.  The patch is issued BEFORE tap 0's W stage, so the in-order counter retires it with tap 2's wait
-  // and tap 2's second barrier publishes it.  Software pipeline over the fragment-read phases of the chunk before the one
-  // that reads the patch (the half of the ping-pong where the wave issues no MFMAs and waits for LDS anyway):
-  //   tap 3: s_load the coefficients, fetch item 0;   tap t = 4 .. 3 + PPW: arithmetic + write-back of item t - 4, fetch
-  //   item t - 3.  Each such phase ends with lgkmcnt(0) -- the wave needs its fragments next anyway -- so the write-back is
-  //   complete before the barrier that follows.
-  typedef float f32x8 __attribute__((ext_vector_type(8)));
-  f32x8 cfa, cfb;                                     // (scale, shift) of channels 0..3 / 4..7 of the group
-  i32x4 raw;
-  bool tr_on = false;
-  const int tr_off = lane * 64 + (((wave & 3) ^ ((lane >> 1) & 3)) << 4) + (wave >> 2) * 4096;
-  auto item_ptr = [&](int i) __attribute__((always_inline)) -> i32x4* {
-    return (i32x4*)(pbase + ((pl - 1) & 1) * PATCH + tr_off + i * 8192);
-  };
-  auto load_coef = [&]() __attribute__((always_inline)) {
-    const float* src = p.gn_coef + ((size_t)pl_img * p.Cin + (size_t)(pl_c - 1) * 32 + (wave & 3) * 8) * 2;
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x20" : "=&s"(cfa), "=&s"(cfb) : "s"(src) : "memory");
-  };
-  auto wait_lgkm = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cfa), "+s"(cfb) : : "memory");
-  };
-  auto transform_raw = [&](int i) __attribute__((always_inline)) {
-    if (tr_mask & (1u << i)) {
-      float f[8];
-      unpack8<T>(raw, f);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f[e] = f[e] * cfa[2 * e] + cfa[2 * e + 1];
-        f[4 + e] = f[4 + e] * cfb[2 * e] + cfb[2 * e + 1];
-      }
-      if (p.gn_silu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
-      }
-      *item_ptr(i) = pack8<T>(f);
-    }
-  };
-  // the GNIN parts of a fragment-read phase: before the fragment reads are issued (whatever the previous tap fetched has
-  // long arrived: this wait costs nothing and must not sit behind the fragment reads) ...
-  auto transform_pre = [&](int tap) __attribute__((always_inline)) {
-    if constexpr (GNIN) {
-      if (tr_on && tap >= 4 && tap <= 3 + PPW) wait_lgkm();
-    }
-  };
-  // ... and after: arithmetic while the fragments are in flight, write-back, next fetch
-  auto transform_tap = [&](int tap) __attribute__((always_inline)) {
-    if constexpr (GNIN) {
-      if (tr_on && tap >= 3) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-          if (tap == 4 + i) transform_raw(i);
-        if (tap == 3) load_coef();
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-          if (tap == 3 + i) raw = *item_ptr(i);
-      }
-    }
-  };
-  // the last write-back is complete before the barrier that ends its tap (earlier ones have whole taps to land)
-  auto transform_post = [&](int tap) __attribute__((always_inline)) {
-    if constexpr (GNIN) {
-      if (tr_on && tap == 3 + PPW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  };
-
   // ---- prologue: patch 0, W(0..2); everything of step 0 landed before the first barrier
   TileC ct = tile_coords(tile0);
   setup_patch(ct);
@@ -407,17 +326,6 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
     wait_for(wy >= 2 ? 2 : wy, 0);                // (the patch is OLDER than every W: retired with W(0))
   }
   bar();
-  if constexpr (GNIN) {
-    load_coef();
-    wait_lgkm();
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      raw = *item_ptr(i);
-      transform_raw(i);
-    }
-    wait_lgkm();
-    bar();
-  }
   // One tile's K walk, as two separate instruction streams (wave groups half a K-step apart); the epilogue stays
   // common code below so that it is inlined once and the accumulators never leave the registers.
   int rs = 0, patch_age = 3;                           // ring slot of step k; taps since the last patch issue
@@ -428,26 +336,17 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
     for (int cc = 0; cc < cpt; ++cc) {
 #pragma unroll 1
       for (int tap = 0; tap < 9; ++tap) {
-        if constexpr (!g1) { transform_pre(tap); reads(rs, (pc & 1), tap); transform_tap(tap); }
+        if constexpr (!g1) reads(rs, (pc & 1), tap);
         bar();
-        if constexpr (!GNIN) {
-          if (wl < total) issue_w();
-        }
-        if (tap == 0) {
-          tr_on = pl < pl_total;
-          if (tr_on) { issue_patch(); patch_age = 0; }
-        }
-        if constexpr (GNIN) {                          // patch first: it is then older than W(k+3), which tap 2 needs
-          if (wl < total) issue_w();
-        }
-        if constexpr (g1) { transform_pre(tap); reads(rs, (pc & 1), tap); transform_tap(tap); }
+        if (wl < total) issue_w();
+        if (tap == 0 && pl < pl_total) { issue_patch(); patch_age = 0; }
+        if constexpr (g1) reads(rs, (pc & 1), tap);
         else mfmas();
         {
           const int wy = wl - (k + 2);                 // W stages younger than W(k+1)
-          wait_for(wy >= 2 ? 2 : (wy < 0 ? 0 : wy), patch_age <= (GNIN ? 1 : 2) ? 1 : 0);
+          wait_for(wy >= 2 ? 2 : (wy < 0 ? 0 : wy), patch_age <= 2 ? 1 : 0);
         }
         if (patch_age < 3) ++patch_age;
-        transform_post(tap);
         bar();
         if constexpr (g1) mfmas();
         rs = rs + 1 == S ? 0 : rs + 1;
@@ -465,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   }
 }
 
-template <typename T, int BM, int BN, bool GNIN, bool F32O = false>
+template <typename T, int BM, int BN, bool F32O = false>
 static int launch_patch(const GemmP& p, hipStream_t st, int gn_chunks) {
   GemmP q = p;
   q.ntm = p.M / BM;
@@ -480,7 +379,7 @@ static int launch_patch(const GemmP& p, hipStream_t st, int gn_chunks) {
   int nwg = q.ntm * q.ntn;
   if (nwg > 256) nwg = 256;
   nwg = (nwg + 7) & ~7;
-  auto kfn = conv_patch_kernel<T, BM, BN, GNIN, F32O>;
+  auto kfn = conv_patch_kernel<T, BM, BN, F32O>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), lds, st, q);
   DFW_CHECK_LAUNCH();
@@ -494,16 +393,16 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
   if (mode == 0) return false;
   if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.ups || p.splitk > 1 || p.batch > 1) return false;
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % 16) != 0 || (p.Cin % 64) != 0) return false;
-  const bool f32o = p.out_mode == DFW_OUT_F32;        // fp32 residual stream: plain (no fused input GroupNorm) tiles only
+  const bool f32o = p.out_mode == DFW_OUT_F32;        // fp32 residual stream
   if ((p.out_mode != DFW_OUT_T && !f32o) || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || (p.res_f32 && !f32o)) return false;
-  if (f32o && (p.gn_coef || (p.ldc % 4) != 0)) return false;
-  if (p.rows_per_img != p.Ho * p.Wo || (p.gn_coef && p.Cin > 1024)) return false;
+  if (f32o && (p.ldc % 4) != 0) return false;
+  if (p.rows_per_img != p.Ho * p.Wo) return false;
   // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  dfw_config.conv_patch = 2 also routes the
   // N % 256 == 0 layers to the 256 x 256 tile: 3 % behind gemm_big with the conflicting LDS swizzle of the first version,
   // 1.5..2 % ahead per kernel with the conflict-free one (1008 / 1222 / 1034 vs 988 / 1198 / 1007 TFLOP/s, same box) and
   // neutral on the whole step (41.96 / 41.90 vs 41.96 / 41.85 ms), so the measured configuration stays the default.
-  // A conv that normalises its input (gn_coef) takes either tile.  0 disables the kernel.
-  const bool only128 = mode != 2 && !p.gn_coef;
+  // 0 disables the kernel.
+  const bool only128 = mode != 2;
   if ((p.N % 256) == 0 && !only128) { bm = 256; bn = 256; }
   else if ((p.N % 128) == 0 && (p.N % 256) != 0) { bm = 512; bn = 128; }
   else return false;
@@ -524,16 +423,12 @@ int launch_conv_patch(const GemmP& p, hipStream_t st) {
   if (!conv_patch_eligible(p, bm, bn)) return DFW_ESHAPE;
   const int chunks = conv_patch_gn_chunks(p);
   const bool bf = p.dtype_bf16 != 0;
-  if (p.gn_coef) {
-    if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, true>(p, st, chunks) : launch_patch<_Float16, 512, 128, true>(p, st, chunks);
-    return bf ? launch_patch<__bf16, 256, 256, true>(p, st, chunks) : launch_patch<_Float16, 256, 256, true>(p, st, chunks);
-  }
   if (p.out_mode == DFW_OUT_F32) {
-    if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, false, true>(p, st, 0) : launch_patch<_Float16, 512, 128, false, true>(p, st, 0);
-    return bf ? launch_patch<__bf16, 256, 256, false, true>(p, st, 0) : launch_patch<_Float16, 256, 256, false, true>(p, st, 0);
+    if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, true>(p, st, 0) : launch_patch<_Float16, 512, 128, true>(p, st, 0);
+    return bf ? launch_patch<__bf16, 256, 256, true>(p, st, 0) : launch_patch<_Float16, 256, 256, true>(p, st, 0);
   }
-  if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, false>(p, st, chunks) : launch_patch<_Float16, 512, 128, false>(p, st, chunks);
-  return bf ? launch_patch<__bf16, 256, 256, false>(p, st, chunks) : launch_patch<_Float16, 256, 256, false>(p, st, chunks);
+  if (bm == 512) return bf ? launch_patch<__bf16, 512, 128>(p, st, chunks) : launch_patch<_Float16, 512, 128>(p, st, chunks);
+  return bf ? launch_patch<__bf16, 256, 256>(p, st, chunks) : launch_patch<_Float16, 256, 256>(p, st, chunks);
 }
 
 }  // namespace dfw

@@ -481,7 +481,6 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   p.nk = a->K / 64; p.cpt = a->Cin / 64; p.ntn = 0; p.ntm = 0;
   p.dtype_bf16 = a->dtype == DFW_BF16;
   p.gn_partial = a->gn_partial; p.gn_groups = a->gn_groups; p.gn_chunks = 0;
-  p.gn_coef = a->gn_in_coef; p.gn_silu = a->gn_in_silu;
   p.conv_chunk_major = a->taps == 9 ? 1 : 0;   // channel-chunk-major K walk (the tap-major one measured 4.5-6 % slower)
   if (p.splitk > p.nk) p.splitk = p.nk;
   plan_gemm(p, p.plan_bm, p.plan_bn);
@@ -498,7 +497,7 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   {
     int pbm = 0, pbn = 0;
     if (conv_patch_eligible(p, pbm, pbn)) {
-      snprintf(buf, n, "conv_patch_kernel<%s,%d,%d%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbm, pbn, p.gn_coef ? ",gn_in" : "");
+      snprintf(buf, n, "conv_patch_kernel<%s,%d,%d>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbm, pbn);
       return 0;
     }
   }
@@ -519,14 +518,6 @@ extern "C" int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a) {
   int pbm = 0, pbn = 0;
   if (conv_patch_eligible(p, pbm, pbn)) return conv_patch_gn_chunks(p);
   return gemm_big_gn_chunks(p);
-}
-
-extern "C" int32_t dfw_gemm_gn_input_ok(const dfw_gemm_args* a) {
-  GemmP p;
-  int esz;
-  if (fill_params(a, p, esz)) return 0;
-  int pbm = 0, pbn = 0;
-  return (p.gn_coef && conv_patch_eligible(p, pbm, pbn)) ? 1 : 0;
 }
 
 extern "C" size_t dfw_gemm_workspace_bytes(const dfw_gemm_args* a) {
@@ -550,7 +541,6 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
     int pbm = 0, pbn = 0;
     if (conv_patch_eligible(p, pbm, pbn)) return launch_conv_patch(p, st);
   }
-  if (p.gn_coef) return DFW_ESHAPE;   // no other kernel normalises its input
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);
   return a->dtype == DFW_BF16 ? launch_gemm<__bf16>(p, st) : launch_gemm<_Float16>(p, st);
 }

@@ -683,7 +683,7 @@ static bool big_cfg_ok(const GemmP& p, const BigCfg& c) {
   if (p.K / c.bk < 4) return false;
   if (p.taps == 9 && (p.Wo % 16 != 0 || p.Ho % (c.bm / 16) != 0)) return false;
   const long long z = p.batch > 1 ? p.batch : 1;
-  return (long long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * z >= (c.occ == 2 ? 256 : 192);
+  return (long long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * z >= (c.occ == 2 ? 256 : cfg().big_min_tiles);
 }
 
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {

@@ -19,7 +19,6 @@ struct GemmP {
   int nk, cpt, ntn, ntm;
   int plan_bm, plan_bn, dtype_bf16;
   float* gn_partial; int gn_groups, gn_chunks;   // fused GroupNorm partial sums of the output (optional)
-  const float* gn_coef; int gn_silu;             // fused GroupNorm(+SiLU) of the input (conv_patch GNIN only)
   int conv_chunk_major;                          // gemm_big conv: K walk = (channel chunk, tap) instead of (tap, chunk)
   int tw, tw_log2, tpr, tpi;  // 2-D output-pixel tiles (conv): tile width, tiles per row / per image; tw == 0: linear rows
 };

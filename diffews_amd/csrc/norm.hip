@@ -12,7 +12,6 @@ namespace dfw {
 // part[b][chunk][g][2].
 struct GnP {
   const char* x; char* y; const float* gamma; const float* beta; float* part; float* mr;
-  float* coef;                                  // optional [B][C][2] (scale, shift) output of finalize
   int B, HW, C, groups, ldx, ldy, chunks, ppc;  // ppc = pixels per chunk
   float eps;
   int silu;
@@ -97,9 +96,7 @@ __global__ void gn_stats_kernel(const GnP p) {
 }
 
 // Finalize: one wave per (image, group) folds the chunk partials in fp64 (lane-strided, then a fixed
-// butterfly) into mean / rstd: mr[b][g][2]; with p.coef it also writes the per-channel affine
-// y = x*scale + shift (scale = rstd*gamma, shift = beta - mean*scale) that conv_halo.hip applies to
-// its input patch in LDS, so the normalised tensor never goes through HBM.
+// butterfly) into mean / rstd: mr[b][g][2].
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
   const int lane = threadIdx.x & 63;
   const int bg = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -123,18 +120,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
     if (var < 0.0) var = 0.0;
     p.mr[bg * 2 + 0] = (float)mean;
     p.mr[bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
-    a = mean;
-    a2 = 1.0 / sqrt(var + (double)p.eps);
-  }
-  if (p.coef) {
-    const float mean = (float)__shfl(a, 0, 64), rstd = (float)__shfl(a2, 0, 64);
-    const int cpg = p.C / p.groups;
-    for (int i = lane; i < cpg; i += 64) {
-      const int c = g * cpg + i;
-      const float sc = rstd * (p.gamma ? p.gamma[c] : 1.f);
-      const float sh = (p.beta ? p.beta[c] : 0.f) - mean * sc;
-      *(float2*)(p.coef + ((size_t)b * p.C + c) * 2) = make_float2(sc, sh);
-    }
   }
 }
 
@@ -278,15 +263,13 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
   int chunks, ppc, threads, slots;
   int rc = gn_geometry(a, chunks, ppc, threads, slots);
   if (rc) return rc;
-  const bool coef_only = a->coef_out != nullptr;   // statistics -> per-channel affine, no apply pass
-  if (!a->stats_ws || (!coef_only && (!a->x || !a->y))) return DFW_EINVAL;
+  if (!a->stats_ws || !a->x || !a->y) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   if (a->stats_ws_bytes < ((size_t)a->B * chunks * a->groups * 2 + (size_t)a->B * a->groups * 2) * sizeof(float))
     return DFW_EWORKSPACE;
   GnP p;
   p.x = (const char*)a->x; p.y = (char*)a->y; p.gamma = a->gamma; p.beta = a->beta;
   p.part = (float*)a->stats_ws;
-  p.coef = a->coef_out;
   p.mr = p.part + (size_t)a->B * chunks * a->groups * 2;
   p.B = a->B; p.HW = a->HW; p.C = a->C; p.groups = a->groups; p.ldx = a->ldx; p.ldy = a->ldy;
   p.chunks = chunks; p.ppc = ppc; p.eps = a->eps; p.silu = a->silu;
@@ -312,22 +295,20 @@ extern "C" int dfw_groupnorm(const dfw_groupnorm_args* a, dfw_stream_t stream) {
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    if (!coef_only) {
-      if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gn_apply_kernel<__bf16, float>), grid, dim3(threads), 0, st, pa);
-      else hipLaunchKernelGGL((gn_apply_kernel<_Float16, float>), grid, dim3(threads), 0, st, pa);
-    }
+    if (a->dtype == DFW_BF16) hipLaunchKernelGGL((gn_apply_kernel<__bf16, float>), grid, dim3(threads), 0, st, pa);
+    else hipLaunchKernelGGL((gn_apply_kernel<_Float16, float>), grid, dim3(threads), 0, st, pa);
   } else if (a->dtype == DFW_BF16) {
     if (!pre) hipLaunchKernelGGL((gn_stats_kernel<__bf16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    if (!coef_only) hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, pa);
+    hipLaunchKernelGGL((gn_apply_kernel<__bf16>), grid, dim3(threads), 0, st, pa);
   } else {
     if (!pre) hipLaunchKernelGGL((gn_stats_kernel<_Float16>), grid, dim3(threads), lds1, st, p);
     DFW_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, gridf, dim3(256), 0, st, p);
     DFW_CHECK_LAUNCH();
-    if (!coef_only) hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, pa);
+    hipLaunchKernelGGL((gn_apply_kernel<_Float16>), grid, dim3(threads), 0, st, pa);
   }
   DFW_CHECK_LAUNCH();
   return 0;

@@ -130,26 +130,20 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
-            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, fuse_gn_in=None, act=L.ACT_NONE,
+            out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, act=L.ACT_NONE,
             out_f32=False):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
-    gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x -- applied
-    by dfw_groupnorm first, or (fuse_gn_in=True, or ops.GN_FUSE_DEFAULT = True) inside the conv
-    kernel where the library supports that for the shape.  The fused form is off by default: measured
-    on MI355X it does not pay yet (conv_patch.hip, GNIN).
+    gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x, applied by dfw_groupnorm first
+    (ResnetBlock2D's norm + nonlinearity + conv as one call; a kernel that normalised its input patch in LDS instead was
+    built in rounds 1-3, never beat pass + conv, and is gone: DESIGN.md section 3).
     out_f32: NHWC fp32 output, and `residual` may be fp32 -- the fp32 residual stream (x + branch summed and stored
     in fp32; the conv's operands stay 16-bit)."""
     assert x.dim() == 4 and x.stride(3) == 1 and x.is_contiguous()
     B, Hi, Wi, Cin = x.shape
-    if fuse_gn_in is None:
-        fuse_gn_in = GN_FUSE_DEFAULT
-    if gn_in is not None and not (fuse_gn_in and not out_f32 and x.dtype != torch.float32
-                                  and (residual is None or residual.dtype == x.dtype)
-                                  and _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk)):
+    if gn_in is not None:
         x = groupnorm(x, *gn_in, out_dtype=w.dtype)
-        gn_in = None
     assert w.shape == (cout, 9 * Cin) and w.dtype == x.dtype and w.is_contiguous()
     if ups:
         assert stride == 1 and pad == 1
@@ -180,9 +174,6 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     a.out_mode = L.OUT_NCHW_F32 if out_nchw_f32 else (L.OUT_F32 if out_f32 else L.OUT_T)
     a.splitk = 0 if splitk is None else splitk
     a.batch, a.dtype = 1, _dt(x)
-    if gn_in is not None:
-        coef = groupnorm_coeff(x, *gn_in[:4])
-        a.gn_in_coef, a.gn_in_silu = coef.data_ptr(), int(gn_in[4])
     stats = None
     if gn_groups and not out_nchw_f32:
         # fused GroupNorm statistics of the output, when the planned kernel supports them
@@ -198,21 +189,6 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
     return out
 
 
-GN_FUSE_DEFAULT = False   # module switch for A/B runs; measured: the fused form does not pay
-
-
-def _gn_input_fusable(x, w, cout, stride, pad, ups, out_nchw_f32, splitk):
-    B, Hi, Wi, Cin = x.shape
-    if stride != 1 or pad != 1 or ups or out_nchw_f32 or splitk:
-        return False
-    a = L.GemmArgs()
-    a.A = a.W = a.C = x.data_ptr()
-    a.gn_in_coef = x.data_ptr()
-    a.a_elems, a.w_elems = x.numel(), w.numel()
-    a.M, a.N, a.K, a.lda, a.ldc = B * Hi * Wi, cout, 9 * Cin, Cin, cout
-    a.taps, a.Cin, a.Hi, a.Wi, a.Ho, a.Wo = 9, Cin, Hi, Wi, Hi, Wi
-    a.stride, a.pad, a.rows_per_img, a.out_scale, a.batch, a.dtype = 1, 1, Hi * Wi, 1.0, 1, _dt(x)
-    return L.lib().dfw_gemm_gn_input_ok(C.byref(a)) == 1
 
 
 def fsa_attention(q, k, v, heads, k_bank=None, v_bank=None, nshot=0, scale=None, out=None, n_plain=0,
@@ -321,13 +297,7 @@ def cross_attention(q, k, v, heads, scale=None):
     return out
 
 
-def groupnorm_coeff(x, gamma, beta, groups, eps):
-    """GroupNorm statistics of x folded with gamma/beta into the per-(image, channel) affine
-    [B, C, 2] = (scale, shift) that conv3x3(gn_in=...) applies to its input inside the kernel."""
-    return groupnorm(x, gamma, beta, groups, eps, _coef_only=True)
-
-
-def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_stats=False, out_dtype=None):
+def groupnorm(x, gamma, beta, groups, eps, silu=False, return_stats=False, out_dtype=None):
     """GroupNorm (+SiLU) over NHWC x [B, H, W, C] (or [B, HW, C]).
     return_stats: also return the (mean, rstd) [B, groups, 2] fp32 the kernel normalised with (training).
     x may be fp32 (the fp32 residual stream): the output is then `out_dtype` (bf16 / fp16, required)."""
@@ -339,13 +309,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, _coef_only=False, return_
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
     a = L.GroupNormArgs()
-    if _coef_only:
-        y = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
-        a.coef_out = y.data_ptr()
-        a.x, a.gamma, a.beta = x.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
-    else:
-        y = torch.empty(x.shape, dtype=odt, device=x.device)
-        a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
+    y = torch.empty(x.shape, dtype=odt, device=x.device)
+    a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta"))
     a.B, a.HW, a.C, a.groups, a.ldx, a.ldy = B, HW, Cc, groups, Cc, Cc
     a.eps, a.silu, a.dtype, a.x_f32 = eps, int(silu), _DT[odt], int(xf32)
     st = getattr(x, "_gn_stats", None)

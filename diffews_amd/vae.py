@@ -32,7 +32,7 @@ class _VaeResnet:
         """x: the residual stream (storage dtype, or fp32 with residual_dtype=torch.float32: see unet._Resnet)."""
         B, H, W, Cin = x.shape
         dt, f32s = self.w1.dtype, x.dtype == torch.float32
-        # norm1/norm2 + SiLU ride inside the convs (normalised in LDS) where the shape allows it
+        # gn_in: GroupNorm + SiLU pass, then the conv; gn_groups: the conv's epilogue leaves the statistics for the next norm
         h = ops.conv3x3(x, self.w1, self.cout, bias=self.cb1, gn_groups=self.groups,
                         gn_in=(self.g1, self.b1, self.groups, 1e-6, True))
         sc = x

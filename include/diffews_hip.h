@@ -53,6 +53,7 @@ typedef struct {
   int32_t gemm_bm, gemm_bn;  /* != 0: force this gemm_kernel tile (128x128, 128x64, 64x64) instead of the cost model */
   int32_t fsa_key_split;     /* 1 (default) split the bank readers' key range when a workspace is passed; 0 never */
   int32_t fsa_force_splits;  /* != 0: this split count for eligible launches (forward and dQ) */
+  int32_t big_min_tiles;     /* gemm_big_kernel only for launches with at least this many tiles (default 192 of the 256 CUs) */
 } dfw_config;
 int dfw_configure(const dfw_config* cfg);
 void dfw_get_config(dfw_config* out);
@@ -101,13 +102,6 @@ typedef struct {
    * of the stored values, gn_partial[img][chunk][group][2] floats, chunk < dfw_gemm_gn_chunks().
    * Only kernels/shapes for which dfw_gemm_gn_chunks() returns > 0 support it. */
   float* gn_partial; int32_t gn_groups;
-  /* Optional fused GroupNorm(+SiLU) of the INPUT: when gn_in_coef != NULL the A operand is
-   * act(x*scale + shift) with (scale, shift) = gn_in_coef[img][cin][2] floats (written by
-   * dfw_groupnorm with coef_out set) and act = SiLU when gn_in_silu != 0; the kernel normalises its
-   * input patch in LDS, so resnet.norm1/norm2 + nonlinearity (diffusers ResnetBlock2D.forward, used at
-   * U:963-1012 and by the VAE) cost no HBM pass.  Only where dfw_gemm_gn_input_ok() returns 1;
-   * dfw_gemm fails with DFW_ESHAPE otherwise. */
-  const float* gn_in_coef; int32_t gn_in_silu;
   /* Optional: output columns n < colscale_n (a multiple of 64) are multiplied by `colscale` instead of
    * out_scale, in fp32 before the single rounding to the storage dtype.  The fused [Wq;Wk;Wv] projection
    * (A:237-245) uses it to hand the attention kernel q * (scale * log2 e): the softmax then needs no
@@ -128,8 +122,6 @@ int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n);
 /* Chunks per image of the fused GroupNorm partial sums this call would emit for gn_groups groups
  * (0: unsupported for this shape / kernel; run dfw_groupnorm's own statistics pass instead). */
 int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a);
-/* 1 when the kernel planned for these arguments can apply gn_in_coef to its input, else 0. */
-int32_t dfw_gemm_gn_input_ok(const dfw_gemm_args* a);
 
 /*
  * KV-fusion self-attention (the DiffewS-specific op): out = softmax(q [k_own ; k_bank]^T * scale) [v_own ; v_bank]
@@ -199,10 +191,6 @@ typedef struct {
   /* Optional: partial sums already produced by the conv that wrote x (dfw_gemm_args.gn_partial),
    * [B][pre_chunks][groups][2] floats; the statistics pass over x is then skipped. */
   const float* pre_partial; int32_t pre_chunks;
-  /* Optional: when coef_out != NULL only the statistics are reduced and the per-channel affine
-   * coef_out[B][C][2] = (rstd*gamma, beta - mean*rstd*gamma) is written; x is not normalised here
-   * (y may be NULL) -- the consumer conv applies it (dfw_gemm_args.gn_in_coef). */
-  float* coef_out;
   /* != 0: x is fp32 [B][HW][ldx floats] (the fp32 residual stream); y stays the storage dtype. */
   int32_t x_f32;
 } dfw_groupnorm_args;

@@ -180,13 +180,10 @@ def test_conv_fused_groupnorm_stats(ops, dtype, B, H, W, Cin, Cout):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("silu", [True, False])
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 160, 160, 64, 128), (3, 128, 128, 128, 256), (1, 224, 224, 256, 512),
-                                            (10, 96, 112, 128, 128), (1, 512, 512, 128, 128), (3, 256, 256, 64, 128),
-                                            (2, 256, 256, 256, 256)])
-def test_conv_fused_groupnorm_input(ops, dtype, silu, B, H, W, Cin, Cout):
-    """conv3x3(gn_in=...) normalises its input patch in LDS (ResnetBlock2D norm+SiLU+conv in one kernel):
-    matches dfw_groupnorm followed by the conv, image borders (zero padding of the NORMALISED
-    tensor) included, and its own output statistics feed the next GroupNorm."""
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 160, 160, 64, 128), (3, 128, 128, 128, 256), (10, 96, 112, 128, 128)])
+def test_conv_groupnorm_input(ops, dtype, silu, B, H, W, Cin, Cout):
+    """conv3x3(gn_in=...) = dfw_groupnorm(+SiLU) followed by the conv (ResnetBlock2D norm + nonlinearity + conv as one call;
+    zero padding of the NORMALISED tensor), and the conv's output statistics feed the next GroupNorm."""
     from diffews_amd.packing import pack_conv3x3
     x = (rnd((B, H, W, Cin), dtype, 1) * 2 + 0.3).cuda()
     w = pack_conv3x3(rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)).cuda()
@@ -194,14 +191,12 @@ def test_conv_fused_groupnorm_input(ops, dtype, silu, B, H, W, Cin, Cout):
     res = rnd((B, H, W, Cout), dtype, 3).cuda()
     g, b = (torch.randn(Cin) * 0.2 + 1).cuda(), (torch.randn(Cin) * 0.2).cuda()
     g2, b2 = (torch.randn(Cout) * 0.2 + 1).cuda(), (torch.randn(Cout) * 0.2).cuda()
-    assert ops._gn_input_fusable(x, w, Cout, 1, 1, False, False, None), "fusion expected for this shape"
-    fused = ops.conv3x3(x, w, Cout, bias=bias, residual=res, gn_groups=32, gn_in=(g, b, 32, 1e-6, silu), fuse_gn_in=True)
+    fused = ops.conv3x3(x, w, Cout, bias=bias, residual=res, gn_groups=32, gn_in=(g, b, 32, 1e-6, silu))
     xn = ops.groupnorm(x, g, b, 32, 1e-6, silu=silu)
     plain = ops.conv3x3(xn, w, Cout, bias=bias, residual=res)
     ref = F.conv2d(xn.float().permute(0, 3, 1, 2), unpack3x3(w, Cin), bias, padding=1).permute(0, 2, 3, 1) + res.float()
     assert rel(plain, ref) < TOL[dtype] and rel(fused, ref) < TOL[dtype]
-    # same normalised bits in LDS; only the fp32 summation order of the K loop differs between kernels
-    assert rel(fused, plain) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert torch.equal(fused, plain)
     assert getattr(fused, "_gn_stats", None) is not None
     n_f = ops.groupnorm(fused, g2, b2, 32, 1e-6, silu=True)
     n_p = ops.groupnorm(plain, g2, b2, 32, 1e-6, silu=True)
