@@ -109,7 +109,8 @@ template <typename T>
 __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dq_kernel(const FsaBwdP p) {
   constexpr int KT = 64, TILE = KT * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];   // [buf][K rows | K tr | V rows]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y;
   int b = (int)gridDim.z - 1 - (int)blockIdx.z, split = 0;      // longest rows (the bank readers, at the end) first
@@ -151,27 +152,32 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dq_kernel(const Fsa
   const int t_end = parted ? tiles_own + (seg1 - 1) * tiles_bank : ntiles;
   // Key-side tiles by LDS-DMA into the double buffer, as in the dK/dV kernel below: per 64-key tile three 8 KiB images
   // [K rows | K tr | V rows], wave w issues pieces w and w + 4 of each (6 instructions), swizzles applied on the source side.
-  const u32x4 rkd = make_srd(p.k, p.kv_bytes);
+  // (per-tile buffer descriptors and loop-constant lane offsets: see the dK/dV kernel)
   const uint32_t lds0 = lds_addr(smem);
+  uint32_t vk[2][2];
+  {
+    const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave + 4 * j) * 8 + lrow;
+      vk[j][0] = (uint32_t)((row * p.ldkv + (slot ^ ((row >> 1) & 7)) * 8) * sizeof(T));            // row image
+      vk[j][1] = (uint32_t)((row * p.ldkv + (slot ^ (((row >> 1) & 1) << 2)) * 8) * sizeof(T));     // transposed-read image
+    }
+  }
   auto issue = [&](int t, int buf) {
     int img = b, tt = t;
     if (t >= tiles_own) { img = bank_b * p.nshot + (t - tiles_own) / tiles_bank; tt = (t - tiles_own) % tiles_bank; }
     const uint32_t dst = lds0 + (uint32_t)buf * (3 * TILE);
-    int lane_i = lane;                       // lane-derived indices behind an opaque copy: never hoisted and spilled across the loop
-    asm volatile("" : "+v"(lane_i));
-    const int lrow = lane_i >> 3, slot = lane_i & 7;
+    const int rows = min(KT, p.n_kv - tt * KT);                  // valid keys of this tile (>= 1)
+    const uint32_t bytes = (uint32_t)(((rows - 1) * p.ldkv + 64) * sizeof(T));
+    const char* kb = p.k + ((size_t)img * p.kvbs + (size_t)tt * KT * p.ldkv + head * 64) * sizeof(T);
+    const u32x4 rk = make_srd(kb, bytes), rv = make_srd(kb + voff, bytes);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = (wave + 4 * j) * 8 + lrow;
-      const int key = tt * KT + row;
-      const bool ok = key < p.n_kv;
-      const int cr = slot ^ ((row >> 1) & 7);                    // row image: chunk of LDS slot `slot`
-      const int ct = slot ^ (((row >> 1) & 1) << 2);             // transposed-read image
-      const size_t kb = (size_t)img * p.kvbs + (size_t)key * p.ldkv + head * 64;
       const uint32_t piece = (uint32_t)(wave + 4 * j) * 1024u;
-      dma16(rkd, ok ? (uint32_t)((kb + cr * 8) * sizeof(T)) : kOOB, dst + piece);
-      dma16(rkd, ok ? (uint32_t)((kb + ct * 8) * sizeof(T)) : kOOB, dst + TILE + piece);
-      dma16(rkd, ok ? (uint32_t)((kb + cr * 8) * sizeof(T)) + voff : kOOB, dst + 2 * TILE + piece);
+      dma16(rk, vk[j][0], dst + piece);
+      dma16(rk, vk[j][1], dst + TILE + piece);
+      dma16(rv, vk[j][0], dst + 2 * TILE + piece);
     }
   };
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -345,35 +351,46 @@ __global__ __launch_bounds__(256) DFW_TWO_WAVES void fsa_bwd_dkv_kernel(const Fs
   const int ntiles_all = nsrc * tiles_q;
   const int t_begin = (int)((long long)qchunk * ntiles_all / p.qsplit), ntiles = (int)((long long)(qchunk + 1) * ntiles_all / p.qsplit);
 
-  const u32x4 rq = make_srd(p.q, p.qkv_bytes), rdo = make_srd(p.dout, p.do_bytes), rst = make_srd(p.stat, p.stat_bytes);
+  // DMA addressing without per-tile vector arithmetic (it was a third of the loop's vector instructions): the buffer
+  // descriptors are rebuilt PER TILE from scalars -- base = the tile's first row in this head's 64 columns, size = up to the
+  // last valid row -- so the lane offsets (row * ld + swizzled chunk) are loop constants and rows past the end of the image
+  // fall outside the descriptor and are zero-filled by the bounds check.
   const uint32_t lds0 = lds_addr(smem);
-  auto issue = [&](int t) {
-    const int img = t < tiles_q ? kimg : src1, tt = t < tiles_q ? t : t - tiles_q;
-    const uint32_t dst = lds0 + (uint32_t)(t & 1) * BUF;
-    int lane_i = lane;                       // lane-derived indices behind an opaque copy: never hoisted and spilled across the loop
-    asm volatile("" : "+v"(lane_i));
-    const int lrow = lane_i >> 3, slot = lane_i & 7;
+  uint32_t vq[2][2], vd[2][2];
+  {
+    const int lrow = lane >> 3, slot = lane & 7;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = (wave + 4 * j) * 8 + lrow;
-      const int qi = tt * QT + row;
-      const bool ok = qi < p.n;
       const int cr = slot ^ ((row >> 1) & 7);                    // row image: chunk of LDS slot `slot`
       const int ct = slot ^ (((row >> 1) & 1) << 2);             // transposed-read image
-      const size_t qb = (size_t)img * p.bs + (size_t)qi * p.ld + head * 64;
-      const size_t db = (size_t)img * p.obs + (size_t)qi * p.ldo + head * 64;
+      vq[j][0] = (uint32_t)((row * p.ld + cr * 8) * sizeof(T));
+      vq[j][1] = (uint32_t)((row * p.ld + ct * 8) * sizeof(T));
+      vd[j][0] = (uint32_t)((row * p.ldo + cr * 8) * sizeof(T));
+      vd[j][1] = (uint32_t)((row * p.ldo + ct * 8) * sizeof(T));
+    }
+  }
+  const uint32_t vst = (uint32_t)lane * 4u;
+  auto issue = [&](int t) {
+    const int img = t < tiles_q ? kimg : src1, tt = t < tiles_q ? t : t - tiles_q;
+    const uint32_t dst = lds0 + (uint32_t)(t & 1) * BUF;
+    const int rows = min(QT, p.n - tt * QT);                     // valid rows of this tile (>= 1)
+    const u32x4 rq = make_srd(p.q + ((size_t)img * p.bs + (size_t)tt * QT * p.ld + head * 64) * sizeof(T),
+                              (uint32_t)(((rows - 1) * p.ld + 64) * sizeof(T)));
+    const u32x4 rdo = make_srd(p.dout + ((size_t)img * p.obs + (size_t)tt * QT * p.ldo + head * 64) * sizeof(T),
+                               (uint32_t)(((rows - 1) * p.ldo + 64) * sizeof(T)));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
       const uint32_t piece = (uint32_t)(wave + 4 * j) * 1024u;
-      dma16(rq, ok ? (uint32_t)((qb + cr * 8) * sizeof(T)) : kOOB, dst + piece);
-      dma16(rq, ok ? (uint32_t)((qb + ct * 8) * sizeof(T)) : kOOB, dst + TILE + piece);
-      dma16(rdo, ok ? (uint32_t)((db + cr * 8) * sizeof(T)) : kOOB, dst + 2 * TILE + piece);
-      dma16(rdo, ok ? (uint32_t)((db + ct * 8) * sizeof(T)) : kOOB, dst + 3 * TILE + piece);
+      dma16(rq, vq[j][0], dst + piece);
+      dma16(rq, vq[j][1], dst + TILE + piece);
+      dma16(rdo, vd[j][0], dst + 2 * TILE + piece);
+      dma16(rdo, vd[j][1], dst + 3 * TILE + piece);
     }
     if (wave == 0) {                         // [-lse | -delta] of the tile's 64 rows: one dword per lane each
-      const int qi = tt * QT + lane_i;
-      const bool ok = qi < p.n;
-      const size_t st = ((size_t)img * p.heads + head) * p.n + qi;
-      dma4(rst, ok ? (uint32_t)((p.stat_half + st) * sizeof(float)) : kOOB, dst + 4 * TILE);
-      dma4(rst, ok ? (uint32_t)(st * sizeof(float)) : kOOB, dst + 4 * TILE + QT * 4);
+      const float* st = p.stat + ((size_t)img * p.heads + head) * p.n + (size_t)tt * QT;
+      dma4(make_srd(st + p.stat_half, (uint32_t)rows * 4u), vst, dst + 4 * TILE);
+      dma4(make_srd(st, (uint32_t)rows * 4u), vst, dst + 4 * TILE + QT * 4);
     }
   };
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
