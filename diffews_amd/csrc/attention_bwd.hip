@@ -19,14 +19,13 @@
 #include "common.h"
 #include "attention_common.h"
 
-#ifndef DFW_FSA_BWD_PRIO
-#define DFW_FSA_BWD_PRIO 1
-#endif
-#if DFW_FSA_BWD_PRIO
-#define DFW_BWD_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define DFW_BWD_PRIO(x) ((void)0)
-#endif
+// Round 3 (counter-driven, profiles/r03_attention_bwd_*): (1) amdgpu_waves_per_eu(2) -- with the 512-register budget of a
+// 256-thread kernel hipcc kept the MFMA accumulators in AGPRs and copied them around the vector work (256 copies per tile);
+// (2) the streamed tiles arrive by LDS-DMA into a double buffer (one barrier per tile, no staging registers), the DMA
+// descriptors rebuilt per tile from scalars so that the lane offsets are loop constants; (3) no per-element masks in full
+// tiles and no s_setprio fences between the stages of a tile, so the compiler overlaps one block's exponentials with the
+// other's MFMAs; (4) a query split of the dK/dV kernel when the key axis is short.  1509 -> 1244 us on the 64x64-level 7-shot
+// launch, 9.2 -> 7.3 ms of attention backward per training step.
 
 namespace dfw {
 
