@@ -1,4 +1,4 @@
-"""Ablation of gemm_big's main loop on a plain GEMM (results are WRONG in the ablated runs; only the time matters).
+"""Ablation of gemm_big's main loop on a plain GEMM: needs the library built with scratch/gemm_big_ablate.patch.txt applied
 mask bits: 1 no DMA issue, 2 no fragment reads, 4 no barriers, 8 no MFMAs."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
