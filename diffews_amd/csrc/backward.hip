@@ -603,7 +603,7 @@ __global__ void gn_bwd_stats_kernel(const GnbP p) {
 }
 
 // fold the pixel chunks per (image, channel): block = 64 channels x 4 chunk lanes, grid (C / 64, B); the sums stay in
-// part[b][0][c]; gn_bwd_param_kernel then adds the images (B terms per channel) into the parameter gradients
+// part[b][0][c]; gn_bwd_group_param_kernel then adds the images (B terms per channel) into the parameter gradients
 __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const GnbP p) {
   __shared__ float red[4][64][2];
   const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
@@ -625,20 +625,24 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const GnbP p) {
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const GnbP p) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.C) return;
-  float dg = 0.f, db = 0.f;
-  for (int b = 0; b < p.B; ++b) {
-    const float* o0 = p.part + (((size_t)b * p.chunks) * p.C + c) * 2;
-    db += o0[0];
-    dg += o0[1];
+// One launch for the two small reductions after the fold: workgroups [0, B * groups) fold a group's channels into the two
+// means the apply pass needs (gs[b][g][2]); the workgroups after them add the images into the parameter gradients, 64
+// channels each.  (They were two launches of 4.7 us each, 61 times per training step.)
+__global__ __launch_bounds__(64) void gn_bwd_group_param_kernel(const GnbP p) {
+  const int ng = p.B * p.groups;
+  if ((int)blockIdx.x >= ng) {
+    const int c = ((int)blockIdx.x - ng) * 64 + threadIdx.x;
+    if (c >= p.C || (!p.dgamma && !p.dbeta)) return;
+    float dg = 0.f, db = 0.f;
+    for (int b = 0; b < p.B; ++b) {
+      const float* o0 = p.part + (((size_t)b * p.chunks) * p.C + c) * 2;
+      db += o0[0];
+      dg += o0[1];
+    }
+    if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * dg;
+    if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * db;
+    return;
   }
-  if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * dg;
-  if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * db;
-}
-
-__global__ __launch_bounds__(64) void gn_bwd_group_kernel(const GnbP p) {
   const int bg = blockIdx.x, b = bg / p.groups, g = bg - b * p.groups;
   const int cpg = p.C / p.groups;
   float a = 0.f, a2 = 0.f;
@@ -796,22 +800,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnbP p) {
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const LnbP p) {   // block = 64 channels x 4 lanes over the blocks
-  __shared__ float red[4][64][2];
-  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const LnbP p) {   // block = 16 channels x 16 lanes over the blocks
+  // (64 channels x 4 lanes left the launch with C / 64 = 5..20 workgroups whose threads walked 64 partial rows one after
+  // the other: 17 us per call, 48 calls per training step)
+  __shared__ float red[16][16][2];
+  const int cl = threadIdx.x & 15, ln = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float a = 0.f, b = 0.f;
-  if (c < p.C)
-    for (int k = lane4; k < p.nblocks; k += 4) {
-      a += p.part[((size_t)k * p.C + c) * 2 + 0];
-      b += p.part[((size_t)k * p.C + c) * 2 + 1];
+  if (c < p.C) {
+    int k = ln;
+    for (; k + 48 < p.nblocks; k += 64) {      // four independent loads in flight per lane
+      const float2 v0 = *(const float2*)(p.part + ((size_t)k * p.C + c) * 2);
+      const float2 v1 = *(const float2*)(p.part + ((size_t)(k + 16) * p.C + c) * 2);
+      const float2 v2 = *(const float2*)(p.part + ((size_t)(k + 32) * p.C + c) * 2);
+      const float2 v3 = *(const float2*)(p.part + ((size_t)(k + 48) * p.C + c) * 2);
+      a += (v0.x + v1.x) + (v2.x + v3.x);
+      b += (v0.y + v1.y) + (v2.y + v3.y);
     }
-  red[lane4][cl][0] = a;
-  red[lane4][cl][1] = b;
+    for (; k < p.nblocks; k += 16) {
+      const float2 v = *(const float2*)(p.part + ((size_t)k * p.C + c) * 2);
+      a += v.x;
+      b += v.y;
+    }
+  }
+  red[ln][cl][0] = a;
+  red[ln][cl][1] = b;
   __syncthreads();
-  if (lane4 == 0 && c < p.C) {
-    a = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
-    b = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+  if (ln == 0 && c < p.C) {
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a += red[i][cl][0]; b += red[i][cl][1]; }
     p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + p.gscale * a;
     p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + p.gscale * b;
   }
@@ -1331,11 +1349,7 @@ extern "C" int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t s
   DFW_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((a->C + 63) / 64, a->B), dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
-  if (a->dgamma || a->dbeta) {
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, p);
-    DFW_CHECK_LAUNCH();
-  }
-  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(a->B * a->groups), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(gn_bwd_group_param_kernel, dim3(a->B * a->groups + ((a->dgamma || a->dbeta) ? (a->C + 63) / 64 : 0)), dim3(64), 0, st, p);
   DFW_CHECK_LAUNCH();
   if (bf) hipLaunchKernelGGL((gn_bwd_apply_kernel<__bf16>), grid, dim3(threads), 0, st, p);
   else hipLaunchKernelGGL((gn_bwd_apply_kernel<_Float16>), grid, dim3(threads), 0, st, p);
@@ -1380,7 +1394,7 @@ extern "C" int dfw_layernorm_bwd(const dfw_layernorm_bwd_args* a, dfw_stream_t s
     else hipLaunchKernelGGL((ln_bwd_kernel<_Float16, 4>), dim3(nb), dim3(256), lds, st, p);
   }
   DFW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((a->C + 63) / 64), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((a->C + 15) / 16), dim3(256), 0, st, p);
   DFW_CHECK_LAUNCH();
   return 0;
 }
