@@ -85,14 +85,14 @@ class GroupNormBwdArgs(C.Structure):
     _fields_ = [("x", _vp), ("dy", _vp), ("dx", _vp), ("gamma", _vp), ("beta", _vp), ("mean_rstd", _vp),
                 ("dgamma", _vp), ("dbeta", _vp), ("workspace", _vp), ("workspace_bytes", _sz),
                 ("B", _i32), ("HW", _i32), ("C", _i32), ("groups", _i32), ("ldx", _i32), ("lddy", _i32), ("lddx", _i32),
-                ("silu", _i32), ("accumulate", _i32), ("grad_scale", _f32), ("dtype", _i32)]
+                ("silu", _i32), ("accumulate", _i32), ("grad_scale", _f32), ("dtype", _i32), ("dx_add", _vp)]
 
 
 class LayerNormBwdArgs(C.Structure):
     _fields_ = [("x", _vp), ("dy", _vp), ("dx", _vp), ("gamma", _vp), ("dgamma", _vp), ("dbeta", _vp),
                 ("workspace", _vp), ("workspace_bytes", _sz),
                 ("rows", _i32), ("C", _i32), ("ldx", _i32), ("lddy", _i32), ("lddx", _i32), ("eps", _f32),
-                ("accumulate", _i32), ("grad_scale", _f32), ("dtype", _i32)]
+                ("accumulate", _i32), ("grad_scale", _f32), ("dtype", _i32), ("dx_add", _vp)]
 
 
 class FsaBwdArgs(C.Structure):

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void colsum_fold_batch_kernel(const ColsumItem
 // Pass 1: per (image, pixel chunk) per-channel (sum dz, sum dz * xhat); pass 2: fold chunks, parameter
 // gradients and the two group means; pass 3: dx.  Thread = 8 fixed channels, like the forward kernels.
 struct GnbP {
-  const char* x; const char* dy; char* dx; const float* gamma; const float* beta; const float* mr;
+  const char* x; const char* dy; char* dx; const char* dxadd; const float* gamma; const float* beta; const float* mr;
   float* part;   // [B][chunks][C][2]
   float* gs;     // [B][groups][2]  (mean_g(gamma dz), mean_g(gamma dz xhat))
   float* dgamma; float* dbeta;
@@ -689,6 +689,12 @@ __global__ void gn_bwd_apply_kernel(const GnbP p) {
       const float dz = p.silu ? fd[i] * silu_grad(ga[i] * xh + be[i]) : fd[i];
       o[i] = rstd[i] * (ga[i] * dz - m1[i] - xh * m2[i]);
     }
+    if (p.dxadd) {       // the gradient x already has from its other consumer: summed here in fp32, one rounding
+      float pv[8];
+      unpack8<T>(*(const i32x4*)(p.dxadd + (((size_t)b * p.HW + px) * p.lddx + cc * 8) * sizeof(T)), pv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] += pv[i];
+    }
     *(i32x4*)(p.dx + (((size_t)b * p.HW + px) * p.lddx + cc * 8) * sizeof(T)) = pack8<T>(o);
   }
 }
@@ -697,7 +703,7 @@ __global__ void gn_bwd_apply_kernel(const GnbP p) {
 // LayerNorm backward: one wave per row (row, dy and the statistics in registers), rows strided over the grid;
 // each wave keeps per-channel partial (dgamma, dbeta) for its rows, folded per block then by ln_bwd_fold_kernel.
 struct LnbP {
-  const char* x; const char* dy; char* dx; const float* gamma; float* part; float* dgamma; float* dbeta;
+  const char* x; const char* dy; char* dx; const char* dxadd; const float* gamma; float* part; float* dgamma; float* dbeta;
   int rows, C, ldx, lddy, lddx, nblocks, accumulate;
   float eps, gscale;
 };
@@ -772,6 +778,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnbP p) {
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (d[i][j] - m1 - f[i][j] * m2);
+        if (p.dxadd) {
+          float pv[8];
+          unpack8<T>(*(const i32x4*)(p.dxadd + (size_t)row * p.lddx * sizeof(T) + ch * 16), pv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += pv[j];
+        }
         *(i32x4*)(orow + ch * 16) = pack8<T>(o);
       }
     }
@@ -1334,7 +1346,7 @@ extern "C" int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t s
   const size_t lds = (size_t)slots * a->C * 2 * sizeof(float);
   if (lds > 64 * 1024) return DFW_ESHAPE;
   GnbP p;
-  p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.dx = (char*)a->dx;
+  p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.dx = (char*)a->dx; p.dxadd = (const char*)a->dx_add;
   p.gamma = a->gamma; p.beta = a->beta; p.mr = a->mean_rstd;
   p.part = (float*)a->workspace;
   p.gs = p.part + (size_t)a->B * chunks * a->C * 2;
@@ -1375,7 +1387,7 @@ extern "C" int dfw_layernorm_bwd(const dfw_layernorm_bwd_args* a, dfw_stream_t s
   const int nb = lnb_blocks(a->rows);
   if (a->workspace_bytes < (size_t)nb * a->C * 2 * sizeof(float)) return DFW_EWORKSPACE;
   LnbP p;
-  p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.dx = (char*)a->dx; p.gamma = a->gamma;
+  p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.dx = (char*)a->dx; p.dxadd = (const char*)a->dx_add; p.gamma = a->gamma;
   p.part = (float*)a->workspace; p.dgamma = a->dgamma; p.dbeta = a->dbeta;
   p.rows = a->rows; p.C = a->C; p.ldx = a->ldx; p.lddy = a->lddy; p.lddx = a->lddx; p.nblocks = nb;
   p.accumulate = a->accumulate; p.eps = a->eps; p.gscale = a->grad_scale;

@@ -123,8 +123,9 @@ class ColsumQueue:
         self.items, self.keep = [], []
 
 
-def groupnorm_bwd(x, dy, mean_rstd, gamma, beta, groups, silu, dgamma=None, dbeta=None, accumulate=False, grad_scale=1.0):
-    """-> dx (like x).  x, dy NHWC (or [B, HW, C]) contiguous; mean_rstd [B, groups, 2] fp32 from the forward."""
+def groupnorm_bwd(x, dy, mean_rstd, gamma, beta, groups, silu, dgamma=None, dbeta=None, accumulate=False, grad_scale=1.0, dx_add=None):
+    """-> dx (like x).  x, dy NHWC (or [B, HW, C]) contiguous; mean_rstd [B, groups, 2] fp32 from the forward.
+    dx_add: a gradient x already has (same memory layout as x), added in the kernel (fp32 sum, one rounding)."""
     assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dtype == dy.dtype
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
@@ -135,6 +136,9 @@ def groupnorm_bwd(x, dy, mean_rstd, gamma, beta, groups, silu, dgamma=None, dbet
     a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
     a.B, a.HW, a.C, a.groups, a.ldx, a.lddy, a.lddx = B, HW, Cc, groups, Cc, Cc, Cc
     a.silu, a.accumulate, a.grad_scale, a.dtype = int(silu), int(accumulate), grad_scale, _dt(x)
+    if dx_add is not None:
+        assert dx_add.is_contiguous() and dx_add.numel() == x.numel() and dx_add.dtype == x.dtype
+        a.dx_add = dx_add.data_ptr()
     lib = L.lib()
     nbytes = lib.dfw_groupnorm_bwd_workspace_bytes(C.byref(a))
     ws = _ws(nbytes, x.device)
@@ -143,7 +147,7 @@ def groupnorm_bwd(x, dy, mean_rstd, gamma, beta, groups, silu, dgamma=None, dbet
     return dx
 
 
-def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5, accumulate=False, grad_scale=1.0):
+def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5, accumulate=False, grad_scale=1.0, dx_add=None):
     assert x.dim() == 2 and dy.shape == x.shape and x.stride(1) == 1 and dy.stride(1) == 1
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     a = L.LayerNormBwdArgs()
@@ -151,6 +155,9 @@ def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5, accumulate=False, grad_
     a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
     a.rows, a.C, a.ldx, a.lddy, a.lddx = x.shape[0], x.shape[1], x.stride(0), dy.stride(0), dx.stride(0)
     a.eps, a.accumulate, a.grad_scale, a.dtype = eps, int(accumulate), grad_scale, _dt(x)
+    if dx_add is not None:     # rows at dx's stride (dx is contiguous)
+        assert dx_add.is_contiguous() and dx_add.numel() == x.numel() and dx_add.dtype == x.dtype
+        a.dx_add = dx_add.data_ptr()
     lib = L.lib()
     nbytes = lib.dfw_layernorm_bwd_workspace_bytes(x.shape[0], x.shape[1])
     ws = _ws(nbytes, x.device)

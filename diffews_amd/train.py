@@ -47,6 +47,14 @@ class _Tape:
         have = self.g.get(k)
         self.g[k] = g if have is None else ob.add(have, g.reshape(have.shape))
 
+    def take(self, t):
+        """Remove and return the gradient t has received so far (None if none, or if it cannot be handed to a kernel as a
+        plain operand): a norm backward adds it inside its kernel (dx_add) instead of a separate add pass."""
+        have = self.g.get(self._key(t))
+        if have is None or not have.is_contiguous() or have.dtype != t.dtype:
+            return None
+        return self.g.pop(self._key(t))
+
     def backward(self, out, dout, after=None):
         """after: called once after every closure that ran (the overlapped gradient all-reduce looks there for parameter
         gradients that just became final)."""
@@ -485,8 +493,9 @@ class UNetTrainer:
         y, mr = ops.groupnorm(x, P.p(gname), P.p(bname), self.groups, eps, silu=silu, return_stats=True)
 
         def bwd(dy):
+            # x's other consumer (the block's residual add, a skip concat) has run already: its gradient rides into the kernel
             tape.accum(x, ob.groupnorm_bwd(x, dy, mr, P.p(gname), P.p(bname), self.groups, silu, P.g(gname), P.g(bname),
-                                           accumulate=P.acc(gname, bname), grad_scale=gs))
+                                           accumulate=P.acc(gname, bname), grad_scale=gs, dx_add=tape.take(x)))
         tape.add(y, bwd)
         return y
 
@@ -495,7 +504,8 @@ class UNetTrainer:
         y = ops.layernorm(x, P.p(gname), P.p(bname))
 
         def bwd(dy):
-            tape.accum(x, ob.layernorm_bwd(x, dy, P.p(gname), P.g(gname), P.g(bname), accumulate=P.acc(gname, bname), grad_scale=gs))
+            tape.accum(x, ob.layernorm_bwd(x, dy, P.p(gname), P.g(gname), P.g(bname), accumulate=P.acc(gname, bname), grad_scale=gs,
+                                           dx_add=tape.take(x)))
         tape.add(y, bwd)
         return y
 

@@ -388,7 +388,10 @@ int dfw_colsum_batch(const void* items, int32_t n_items, int64_t total_blocks1, 
 
 /* GroupNorm(+SiLU) backward (torch.nn.GroupNorm + F.silu under autograd; ResnetBlock2D.norm1/norm2,
  * Transformer2DModel.norm, conv_norm_out).  mean_rstd [B][groups][2] are the forward's statistics
- * (the tail of dfw_groupnorm's stats_ws).  dgamma / dbeta may be NULL. */
+ * (the tail of dfw_groupnorm's stats_ws).  dgamma / dbeta may be NULL.
+ * dx_add (optional, laid out like dx): a gradient x has already received from another consumer (the residual add that
+ * follows the block: pre-norm blocks reach their input's gradient through a norm backward LAST); dx = computed + dx_add,
+ * summed in fp32 and rounded once -- the separate add pass over the activation is gone. */
 typedef struct {
   const void* x; const void* dy; void* dx; const float* gamma; const float* beta; const float* mean_rstd;
   float* dgamma; float* dbeta;
@@ -397,12 +400,14 @@ typedef struct {
   int32_t silu, accumulate;
   float grad_scale;
   int32_t dtype;
+  const void* dx_add;
 } dfw_groupnorm_bwd_args;
 
 int dfw_groupnorm_bwd(const dfw_groupnorm_bwd_args* a, dfw_stream_t stream);
 size_t dfw_groupnorm_bwd_workspace_bytes(const dfw_groupnorm_bwd_args* a);
 
-/* LayerNorm backward (BasicTransformerBlock.norm1/2/3); statistics are recomputed from x. */
+/* LayerNorm backward (BasicTransformerBlock.norm1/2/3); statistics are recomputed from x.  dx_add: as above (rows at
+ * stride lddx). */
 typedef struct {
   const void* x; const void* dy; void* dx; const float* gamma; float* dgamma; float* dbeta;
   void* workspace; size_t workspace_bytes;
@@ -411,6 +416,7 @@ typedef struct {
   int32_t accumulate;
   float grad_scale;
   int32_t dtype;
+  const void* dx_add;
 } dfw_layernorm_bwd_args;
 
 int dfw_layernorm_bwd(const dfw_layernorm_bwd_args* a, dfw_stream_t stream);

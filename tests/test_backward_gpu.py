@@ -109,6 +109,10 @@ def test_groupnorm_backward(B, dtype, silu, Bn, HW, C):
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     dx = ob.groupnorm_bwd(x.cuda(), dy.cuda(), mr, gamma.cuda(), beta.cuda(), G, silu, dg, db)
     assert rel(dx, xr.grad) < 2 * TOL[dtype]
+    # dx_add: the gradient x already has from its other consumer, summed inside the kernel (fp32, one rounding)
+    prev = rnd(tuple(x.shape), dtype, 9).cuda()
+    dx2 = ob.groupnorm_bwd(x.cuda(), dy.cuda(), mr, gamma.cuda(), beta.cuda(), G, silu, dx_add=prev)
+    assert rel(dx2, xr.grad + prev.float().cpu()) < 2 * TOL[dtype]
     assert rel(dg, gr.grad) < 2e-3 and rel(db, br.grad) < 2e-3      # fp32 sums of fp32 terms (xhat from 16-bit x)
 
 
@@ -123,6 +127,10 @@ def test_layernorm_backward(B, dtype, rows, C):
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     dx = ob.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), dg, db)
     assert rel(dx, xr.grad) < TOL[dtype]
+    prev = rnd(tuple(x.shape), dtype, 9).cuda()
+    dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)
+    dx2 = ob.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), dg2, db2, dx_add=prev)
+    assert rel(dx2, xr.grad + prev.float().cpu()) < TOL[dtype] and torch.equal(dg2, dg)
     assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
 
 
