@@ -146,17 +146,35 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   typename Tr<T>::v8 fa6[MB6], fw6[NB6];
   const uint32_t rw6 = (uint32_t)(wn * 64 + l15) * RB + (uint32_t)((l4 ^ ((l15 >> 1) & 3)) << 4);
   const int q00 = (wm * (WTM / 16)) * PW + l15;          // patch pixel of this lane for pixel-row block 0, tap (0, 0)
-  auto reads = [&](int slot, int pbuf, int tap) __attribute__((always_inline)) {
+  // A-fragment addresses without per-tap arithmetic (it was 45 vector instructions per tap in the fragment-read half of the
+  // ping-pong, i.e. in the half that has to finish inside the partner's 32 MFMAs).  Pixel of (tap (ky, kx), row block i):
+  // q = (q00 + kx) + 18 s with s = ky + i; 18 s is even, so q >> 1 = ((q00 + kx) >> 1) + 9 s and the swizzle term
+  // (q >> 1) & 3 = (h_kx + s) & 3 with h_kx = ((q00 + kx) >> 1) & 3: per kx four lane-constant bases (one per s & 3), and
+  // s * 18 * 64 bytes is an immediate of the ds_read once the nine taps are unrolled.
+  // The twelve bases are rebuilt once per 32-channel chunk (36 vector instructions per nine taps) behind an opaque copy of the
+  // lane id: kept as loop constants they would cost twelve more registers than this kernel has.
+  uint32_t ab[3][4];
+  auto set_patch_buf = [&](int pbuf) __attribute__((always_inline)) {
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int l15o = lane_o & 15, l4o = lane_o >> 4;
+    const uint32_t o = (uint32_t)(S * WSTAGE + pbuf * PATCH);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int qk = (wm * (WTM / 16)) * PW + l15o + kx, h = (qk >> 1) & 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ab[kx][r] = (uint32_t)(qk * RB + ((l4o ^ ((h + r) & 3)) << 4)) + o;
+    }
+  };
+  auto reads = [&](int slot, int tap) __attribute__((always_inline)) {    // tap: compile-time (the tap loop is unrolled)
     const char* bw = smem + slot * WSTAGE + rw6;
 #pragma unroll
     for (int j = 0; j < NB6; ++j) fw6[j] = as_v8<T>(*(const i32x4*)(bw + j * 16 * RB));
     const int ky = tap / 3, kx = tap - ky * 3;
-    const char* pb = pbase + pbuf * PATCH;
-    const int qb = q00 + ky * PW + kx;
 #pragma unroll
     for (int i = 0; i < MB6; ++i) {
-      const int q = qb + i * PW;
-      fa6[i] = as_v8<T>(*(const i32x4*)(pb + q * RB + ((l4 ^ ((q >> 1) & 3)) << 4)));
+      const int sidx = ky + i;
+      fa6[i] = as_v8<T>(*(const i32x4*)(smem + ab[kx][sidx & 3] + sidx * PW * RB));
     }
   };
   auto mfmas = [&]() __attribute__((always_inline)) {
@@ -334,13 +352,14 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
     constexpr bool g1 = decltype(G1)::value;
 #pragma unroll 1
     for (int cc = 0; cc < cpt; ++cc) {
-#pragma unroll 1
+      set_patch_buf(pc & 1);
+#pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        if constexpr (!g1) reads(rs, (pc & 1), tap);
+        if constexpr (!g1) reads(rs, tap);
         bar();
         if (wl < total) issue_w();
         if (tap == 0 && pl < pl_total) { issue_patch(); patch_age = 0; }
-        if constexpr (g1) reads(rs, (pc & 1), tap);
+        if constexpr (g1) reads(rs, tap);
         else mfmas();
         {
           const int wy = wl - (k + 2);                 // W stages younger than W(k+1)
