@@ -416,11 +416,11 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
   if ((p.out_mode != DFW_OUT_T && !f32o) || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || (p.res_f32 && !f32o)) return false;
   if (f32o && (p.ldc % 4) != 0) return false;
   if (p.rows_per_img != p.Ho * p.Wo) return false;
-  // Default: the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there).  dfw_config.conv_patch = 2 also routes the
-  // N % 256 == 0 layers to the 256 x 256 tile: 3 % behind gemm_big with the conflicting LDS swizzle of the first version,
-  // 1.5..2 % ahead per kernel with the conflict-free one (1008 / 1222 / 1034 vs 988 / 1198 / 1007 TFLOP/s, same box) and
-  // neutral on the whole step (41.96 / 41.90 vs 41.96 / 41.85 ms), so the measured configuration stays the default.
-  // 0 disables the kernel.
+  // dfw_config.conv_patch: 1 = the 512 x 128 tile for the N = 128 layers only (+8..11 % over gemm_big there), 2 (default since the
+  // fragment addresses became per-chunk bases + immediates) also the N % 256 == 0 layers on the 256 x 256 tile: +7..12 % per
+  // kernel against gemm_big (vae256 0.997 -> 0.914 ms, vae128 0.791 -> 0.739, 128 -> 256 @256^2 0.469 -> 0.417) and 42.0 -> 41.3 ms
+  // on the inference step; with the 45-instruction address block per tap it had been 1.5..2 % ahead per kernel and neutral on
+  // the step.  0 disables the kernel.
   const bool only128 = mode != 2;
   if ((p.N % 256) == 0 && !only128) { bm = 256; bn = 256; }
   else if ((p.N % 128) == 0 && (p.N % 256) != 0) { bm = 512; bn = 128; }
