@@ -99,7 +99,7 @@ class FsaBwdArgs(C.Structure):
     _fields_ = [("qkv", _vp), ("out", _vp), ("dout", _vp), ("lse", _vp), ("delta", _vp), ("dqkv", _vp),
                 ("batch", _i32), ("heads", _i32), ("n", _i32), ("nshot", _i32), ("n_plain", _i32),
                 ("ld", _i32), ("ldo", _i32), ("ldd", _i32), ("scale", _f32), ("dtype", _i32),
-                ("workspace", _vp), ("workspace_bytes", _sz)]
+                ("workspace", _vp), ("workspace_bytes", _sz), ("delta_bytes", _sz)]
 
 
 class XattnBwdArgs(C.Structure):
@@ -117,7 +117,7 @@ class AttnBwdArgs(C.Structure):
                 ("batch", _i32), ("heads", _i32), ("n_q", _i32), ("n_kv", _i32),
                 ("ldq", _i32), ("ldkv", _i32), ("ldo", _i32), ("lddq", _i32), ("lddkv", _i32),
                 ("q_bs", _i64), ("kv_bs", _i64), ("o_bs", _i64), ("dq_bs", _i64), ("dkv_bs", _i64),
-                ("scale", _f32), ("dtype", _i32), ("workspace", _vp), ("workspace_bytes", _sz)]
+                ("scale", _f32), ("dtype", _i32), ("workspace", _vp), ("workspace_bytes", _sz), ("delta_bytes", _sz)]
 
 
 class AdamWArgs(C.Structure):

@@ -792,6 +792,7 @@ extern "C" size_t dfw_fsa_attention_bwd_workspace_bytes(const dfw_fsa_bwd_args* 
 extern "C" int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream) {
   if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->delta || !a->dqkv) return DFW_EINVAL;
   if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->nshot < 0 || a->n_plain < 0 || a->n_plain > a->batch) return DFW_EINVAL;
+  if (a->delta_bytes < 2ull * (size_t)a->batch * (size_t)a->heads * (size_t)a->n * sizeof(float)) return DFW_EWORKSPACE;
   if (a->nshot > 0 && (a->n_plain <= 0 || (a->batch - a->n_plain) * a->nshot != a->n_plain)) return DFW_EINVAL;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   const int C = a->heads * 64;
@@ -872,6 +873,7 @@ extern "C" size_t dfw_attention_bwd_workspace_bytes(const dfw_attn_bwd_args* a) 
 extern "C" int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->out || !a->dout || !a->lse || !a->delta || !a->dq || !a->dk || !a->dv) return DFW_EINVAL;
   if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_kv <= 0) return DFW_EINVAL;
+  if (a->delta_bytes < 2ull * (size_t)a->batch * (size_t)a->heads * (size_t)a->n_q * sizeof(float)) return DFW_EWORKSPACE;
   if (a->dtype != DFW_BF16 && a->dtype != DFW_F16) return DFW_EINVAL;
   const int C = a->heads * 64;
   if ((a->ldq | a->ldkv | a->ldo | a->lddq | a->lddkv) % 8 != 0) return DFW_ESHAPE;

@@ -440,8 +440,8 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   if (a->out_mode == DFW_OUT_T && (a->N % 4 == 0) && (a->ldc % 4 != 0)) return DFW_ESHAPE;
   if (a->residual && (a->N % 4 == 0) && (a->ldr % 4 != 0)) return DFW_ESHAPE;
   if (a->residual_f32 && (!a->residual || a->N % 4 != 0 || a->ldr % 4 != 0 || ((uintptr_t)a->residual & 15) || a->act != DFW_ACT_NONE ||
-                          a->colscale_n > 0 || a->out_mode == DFW_OUT_NCHW_F32))
-    return DFW_ESHAPE;
+                          a->colscale_n > 0 || a->out_mode == DFW_OUT_NCHW_F32 || a->geglu))
+    return DFW_ESHAPE;     // (GEGLU epilogues exist in the 16-bit-residual instantiations only: they would read the fp32 residual as 16-bit data)
   if (a->rowbias && a->ld_rowbias > 0 && (a->ld_rowbias % 4 != 0 || a->ld_rowbias < a->N)) return DFW_ESHAPE;
   if (a->a_elems <= 0 || a->w_elems <= 0) return DFW_EINVAL;
   if (a->a_elems * esz >= (1ll << 31) || a->w_elems * esz >= (1ll << 31)) return DFW_ERANGE;

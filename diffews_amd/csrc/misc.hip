@@ -868,7 +868,7 @@ extern "C" void dfw_get_config(dfw_config* out) {
   if (out) *out = g_cfg;
 }
 
-extern "C" int dfw_version(void) { return 102; }
+extern "C" int dfw_version(void) { return 103; }
 
 extern "C" const char* dfw_error_string(int code) {
   switch (code) {

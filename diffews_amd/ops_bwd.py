@@ -256,6 +256,7 @@ def fsa_attention_bwd(qkv, out, dout, lse, heads, nshot=0, n_plain=0, scale=None
     delta = torch.empty(2, B, heads, N, dtype=torch.float32, device=qkv.device)   # (-delta | -lse), see the header
     a = L.FsaBwdArgs()
     a.qkv, a.out, a.dout, a.lse, a.delta, a.dqkv = qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr()
+    a.delta_bytes = delta.numel() * 4
     a.batch, a.heads, a.n, a.nshot, a.n_plain = B, heads, N, nshot, n_plain
     a.ld, a.ldo, a.ldd = C3, Cq, C3
     a.scale = scale if scale is not None else 64 ** -0.5
@@ -295,6 +296,7 @@ def attention_bwd(q, k, v, out, dout, lse, heads, dk_out, dv_out, scale=None, q_
     delta = torch.empty(2, B, heads, N, dtype=torch.float32, device=q.device)
     a = L.AttnBwdArgs()
     a.q, a.k, a.v, a.out, a.dout, a.lse, a.delta = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    a.delta_bytes = delta.numel() * 4
     a.dq, a.dk, a.dv = dq.data_ptr(), dk_out.data_ptr(), dv_out.data_ptr()
     a.batch, a.heads, a.n_q, a.n_kv = B, heads, N, Lc
     a.ldq, a.ldkv, a.ldo, a.lddq, a.lddkv = q.stride(1), k.stride(1), Cq, Cq, dk_out.stride(1)

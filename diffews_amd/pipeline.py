@@ -107,6 +107,20 @@ class MarigoldPipelineRGBLatentNoise:
                         image_encoder=None, torch_dtype=None, residual_dtype=None, **kw):
         from .unet import MyUNet2DConditionModel
         from .vae import AutoencoderKL
+        requested = torch_dtype
+        if torch_dtype == torch.float32:
+            # The launcher's DEFAULT (evaluation_util/main_oss.py:332-336: `dtype = torch.float32` unless
+            # --half_precision) reaches this call as torch_dtype=torch.float32 beside prebuilt unet= / vae=
+            # (E:355-369).  The engine has no fp32-operand kernels; what it offers for an
+            # fp32 request is its most precise mode, fp16 storage + fp32 residual stream: z0 within north_star's
+            # 1e-3 of the fp32 path (7.4-7.7e-4).  Selected here, loudly, instead of
+            # silently staying in whatever 16-bit dtype the engines were built with.
+            import warnings
+            warnings.warn("torch_dtype=torch.float32: the MI355X engine computes with 16-bit MFMA operands; running its "
+                          "parity mode (fp16 storage + fp32 residual stream, z0 within 1e-3 of fp32) instead", stacklevel=2)
+            torch_dtype = torch.float16
+            if residual_dtype is None:
+                residual_dtype = torch.float32
         dt = torch_dtype or torch.bfloat16
         if text_embeds is None and text_encoder is None:
             # evaluation_util/main_oss.py:355-369 passes text_embeds=None and no text_encoder: diffusers then
@@ -119,9 +133,18 @@ class MarigoldPipelineRGBLatentNoise:
             vae = AutoencoderKL.from_pretrained(checkpoint, subfolder="vae", torch_dtype=dt, residual_dtype=residual_dtype)
         if scheduler is None:
             scheduler = DDIMSchedulerCustomized.from_pretrained(checkpoint, subfolder="scheduler")
-        return cls(unet, vae, scheduler, tokenizer=tokenizer, text_embeds=text_embeds, text_encoder=text_encoder,
+        # prebuilt engines (the launcher's call form, E:338-349) follow an EXPLICIT torch_dtype / residual_dtype: they
+        # are repacked from their host state dict once (`to`), the residual-stream mode is a flag
+        if requested is not None:
+            unet.to(dtype=dt)
+            vae.to(dtype=dt)
+        pipe = cls(unet, vae, scheduler, tokenizer=tokenizer, text_embeds=text_embeds, text_encoder=text_encoder,
                    image_encoder=image_encoder, image_projector=image_projector, controlnet=controlnet,
                    customized_head=customized_head)
+        if residual_dtype is not None and (unet.residual_dtype != residual_dtype or vae.residual_dtype != residual_dtype):
+            pipe.set_residual_dtype(residual_dtype)
+        pipe.requested_dtype = requested
+        return pipe
 
     def to(self, device=None, dtype=None):
         self.unet.to(device, dtype)

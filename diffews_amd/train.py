@@ -182,6 +182,7 @@ class UNetTrainer:
         self._overflow_pending = None
         self._param, self._master_seen, self._pending_ref, self.reducer = None, 0, None, None
         self._graphs = {}
+        self.graph_recaptures = 0     # captured steps dropped and re-captured because the loss scale changed
         self._cs = ob.ColsumQueue()
         self.training = True
         self.step_count = 0
@@ -747,8 +748,18 @@ class UNetTrainer:
         flags, derived-weight table) is identical for every step, which is what makes the capture valid."""
         self._resolve_overflow()
         ins = [t.to(self.device, torch.float32).contiguous() for t in (z_refcat, z_tag, target)] + [ehs.to(self.device).contiguous()]
-        key = (tuple(tuple(t.shape) for t in ins), float(timestep), self.loss_scale)
+        # The loss scale is baked into the captured launches as a host argument, so a graph serves ONE scale.  It is not part
+        # of the cache key: under a dynamic scale (fp16 default) every halving / doubling would otherwise leave a ~2 200-node
+        # graph with its private activation pool behind (up to 17 scales, HBM growing until the allocator gives up).  A scale
+        # change drops the stale graph -- its pool goes back to the allocator -- and re-captures at the new scale.
+        key = (tuple(tuple(t.shape) for t in ins), float(timestep))
         ent = self._graphs.get(key)
+        if ent is not None and ent[4] != self.loss_scale:
+            del self._graphs[key]
+            ent[0].reset()
+            ent = None
+            self.graph_recaptures += 1
+            torch.cuda.empty_cache()
         if ent is None:
             static = [t.clone() for t in ins]
             cur = torch.cuda.current_stream(self.device)
@@ -773,9 +784,9 @@ class UNetTrainer:
             from .pipeline import _assert_no_memset_nodes
             self.graph_nodes = _assert_no_memset_nodes(graph)
             graph.instantiate()
-            ent = (graph, static, loss, pred)
+            ent = (graph, static, loss, pred, self.loss_scale)
             self._graphs[key] = ent
-        graph, static, loss, pred = ent
+        graph, static, loss, pred, _ = ent
         for dst, src in zip(static, ins):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
@@ -852,6 +863,29 @@ class UNetTrainer:
             if self.dynamic_loss_scale and self._good_steps >= self.growth_interval:
                 self.loss_scale = min(65536.0, self.loss_scale * 2.0)
                 self._good_steps = 0
+
+    def step_guard(self):
+        """fp16 on the autograd call surface (`loss.backward()` + `torch.optim`, INTEGRATION.md path (a)): GradScaler's
+        found-inf check, which accelerate performs inside `optimizer.step()` at T:1394 and which a plain torch.optim does
+        NOT -- an overflowed fp16 step leaves inf / NaN in `parameters()[0].grad`, `clip_grad_norm_` turns the whole
+        gradient into NaN and AdamW writes NaN into the fp32 master for good.  Call it between `loss.backward()` and
+        `clip_grad_norm_`; it returns True when the gradient is finite (take the step).  On overflow it returns False --
+        the caller skips `optimizer.step()` -- after zeroing the gradient and applying the dynamic loss scale's rule (halve
+        now, double after `growth_interval` clean steps).  One host sync on a scalar.  `optimizer_step()` (path (b)) does
+        the same on the device without the sync and needs no guard."""
+        finite = bool(torch.isfinite(ob.sumsq(self.P.grad)).all())
+        if finite:
+            self._good_steps += 1
+            if self.dynamic_loss_scale and self._good_steps >= self.growth_interval:
+                self.loss_scale = min(65536.0, self.loss_scale * 2.0)
+                self._good_steps = 0
+        else:
+            self.skipped_steps += 1
+            self._good_steps = 0
+            if self.dynamic_loss_scale:
+                self.loss_scale = max(1.0, self.loss_scale * 0.5)
+            self.P.grad.zero_()
+        return finite
 
     def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0):
         """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers; the 16-bit shadow is refreshed in the same pass.
@@ -950,6 +984,11 @@ class _QueryPass(torch.autograd.Function):
         n_ref = c["n_ref"]
         ob.loss_grad(g.to(torch.float32).contiguous(), tr.dtype, scale=tr.loss_scale, dpred_out=c["dpred"][n_ref:],
                      dpred_nchw_out=c["dpn"][n_ref:])
+        if tr.reducer is not None:
+            # the autograd call surface (`loss.backward()`, T:1390): the loss value lives in the caller's graph, not here, so
+            # the tail slot carries 0 and the caller averages its own loss (T:1387 `accelerator.gather(loss)`); the buckets
+            # fire during the tape walk exactly as under forward_backward(reducer=...)
+            tr.reducer.begin(None)
         tr._backward(c, tr.reducer)
         ctx.prm.grad = tr.P.grad          # the flat fp32 gradient (packed layout), for clip_grad_norm_ / torch.optim
         ctx.c = None
@@ -1025,18 +1064,28 @@ class GradBucketReducer:
         self.comm = torch.cuda.Stream(device=buf.device) if self.cuda else None
         self.fired_order = []
         self.active = False
+        self.steps_begun = 0                          # begin() calls so far (tests / launch-loop sanity checks)
 
     def begin(self, loss=None):
+        """Start of a backward walk.  loss: the scalar to average with the last bucket (None: the slot carries 0)."""
         self.left = [set(s) for s in self.need]
         self.fired = [False] * len(self.ranges)
         self.fired_order = []
         self.active = True
+        self.steps_begun += 1
+        slot = self.buf[self.loss_slot:self.loss_slot + 1]
         if loss is not None:                          # before any bucket can fire: the loss is known ahead of the backward
-            self.buf[self.loss_slot:self.loss_slot + 1].copy_(loss.reshape(1).to(self.buf.dtype))
+            slot.copy_(loss.reshape(1).to(self.buf.dtype))
+        else:
+            slot.zero_()
 
     def mark(self, names):
         if not self.active:
-            return
+            # a reducer that is attached to a backward walk but was never begun would let every rank keep its LOCAL
+            # gradient without any error (the ranks then diverge silently): refuse
+            raise RuntimeError("GradBucketReducer.mark() without begin(): the gradient buckets of this step would never be "
+                               "reduced -- call begin() before the backward (forward_backward(reducer=...) and the autograd "
+                               "surface with `trainer.reducer` set do)")
         for name in names:
             for b in self.of.get(name, ()):
                 self.left[b].discard(name)
@@ -1084,11 +1133,13 @@ class GradBucketReducer:
     def finish(self):
         """Issue the buckets that are still open (parameters nobody wrote this step), then join the streams.
         Returns the rank-averaged loss tensor [1] (a view of the tail slot)."""
-        if self.active:
-            for b in range(len(self.ranges) - 1, -1, -1):
-                if not self.fired[b]:
-                    self._fire(b)
-            self.active = False
+        if not self.active:
+            raise RuntimeError("GradBucketReducer.finish() without a begun step: no backward walk reported to this reducer "
+                               "since the last finish() -- the gradient in the buffer has NOT been reduced")
+        for b in range(len(self.ranges) - 1, -1, -1):
+            if not self.fired[b]:
+                self._fire(b)
+        self.active = False
         if self.cuda:
             torch.cuda.current_stream(self.buf.device).wait_stream(self.comm)
         return self.buf[self.loss_slot:self.loss_slot + 1]

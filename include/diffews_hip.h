@@ -471,6 +471,10 @@ typedef struct {
   /* Optional scratch of dfw_fsa_attention_bwd_workspace_bytes() (16-byte aligned): the dQ kernel then splits the key range
    * of the bank-reading images over several workgroups (partial dQ in fp32, summed in order), as the forward does. */
   void* workspace; size_t workspace_bytes;
+  /* Bytes behind `delta` (version >= 103): must be >= 2 * batch * heads * n * sizeof(float), else DFW_EWORKSPACE -- the
+   * scratch doubled in version 102, and a caller still sized for the single array must get an error, not a device write
+   * past its buffer. */
+  size_t delta_bytes;
 } dfw_fsa_bwd_args;
 
 int dfw_fsa_attention_bwd(const dfw_fsa_bwd_args* a, dfw_stream_t stream);
@@ -493,6 +497,7 @@ typedef struct {
    * itself): with a short key axis (77 prompt tokens = one key block per image and head) the dK/dV kernel then splits the
    * query rows over several workgroups per key block (fp32 partials, summed in order: still deterministic). */
   void* workspace; size_t workspace_bytes;
+  size_t delta_bytes;   /* bytes behind `delta`: >= 2 * batch * heads * n_q * sizeof(float), else DFW_EWORKSPACE (version >= 103) */
 } dfw_attn_bwd_args;
 
 int dfw_attention_bwd(const dfw_attn_bwd_args* a, dfw_stream_t stream);

@@ -545,6 +545,37 @@ def test_optimizer_skips_overflow_and_halves_the_loss_scale(hip_lib):
     assert torch.equal(m0, tb.P.master) and tb.skipped_steps == 1 and tb.step_count == 0 and tb.loss_scale == 1.0
 
 
+def test_step_guard_skips_an_overflowed_fp16_step_on_the_autograd_surface(hip_lib):
+    """INTEGRATION.md path (a) under fp16: `loss.backward()` -> `unet.step_guard()` -> clip + `torch.optim` step.  A huge
+    loss scale overflows the fp16 backward: the guard reports it, zeroes the gradient and halves the scale; the launcher
+    skips `optimizer.step()` and the fp32 master stays finite and unchanged.  The next (clean) step passes the guard."""
+    import torch.nn.functional as F
+    from diffews_amd.train import UNetTrainer
+    dtype = torch.float16
+    ucfg, usd, _, z_refcat, z_tag, target, ehs = _train_setup(dtype, 1, 1, seed=17)
+    unet = UNetTrainer(ucfg, usd, torch_dtype=dtype, loss_scale=65536.0 * 65536.0)
+    optimizer = torch.optim.AdamW(unet.parameters(), lr=1e-4)
+    ts = torch.tensor([1]).long().cuda()
+
+    def launcher_step():
+        pr = unet(z_refcat.cuda(), ts, ehs.cuda(), is_target=False).sample
+        pq = unet(z_tag.cuda(), ts, ehs.cuda(), is_target=True).sample
+        loss = F.mse_loss(pq.float() + pr.float() * 0., target.cuda().float(), reduction="mean")
+        loss.backward()
+        took = unet.step_guard()
+        if took:
+            torch.nn.utils.clip_grad_norm_(unet.parameters(), 1.0)
+            optimizer.step()
+        optimizer.zero_grad()
+        return took
+    m0 = unet.P.master.clone()
+    assert launcher_step() is False
+    assert unet.loss_scale == 65536.0 * 32768.0 and unet.skipped_steps == 1 and torch.equal(unet.P.master, m0)
+    unet.loss_scale = 1024.0
+    assert launcher_step() is True
+    assert torch.isfinite(unet.P.master).all() and not torch.equal(unet.P.master, m0)
+
+
 def test_trainer_state_resume_is_bit_exact(hip_lib, tmp_path):
     """save_state / load_state (accelerator.save_state / load_state, T:1281-1309, T:1407-1431): weights in the diffusers
     layout + optimizer state; a trainer rebuilt from the checkpoint continues the SAME trajectory bit for bit."""
@@ -613,6 +644,48 @@ def test_gradient_buckets_are_reduced_after_their_last_writer(hip_lib):
     assert ParamStore.TAIL >= 1
 
 
+def test_autograd_surface_reduces_every_bucket_with_attached_reducer(hip_lib):
+    """`trainer.reducer = trainer.make_reducer(...)` + the launcher's own `unet(...)` / `loss.backward()` (T:1374-1391): the
+    backward of the query pass must BEGIN the reducer, so that every gradient bucket goes through the collective during the
+    tape walk (round-3 defect: nothing called begin(), mark() returned silently and each rank kept its local gradient).
+    Injected collective = x2 (a 2-rank SUM of equal gradients): after finish() the flat gradient, averaged by 1 / world,
+    equals the unreduced one bit for bit and every bucket fired; a reducer that was never begun refuses to finish()."""
+    import torch.nn.functional as F
+    from diffews_amd.train import UNetTrainer
+    dtype = torch.bfloat16
+    ucfg, usd, _, z_refcat, z_tag, target, ehs = _train_setup(dtype, 1, 2, seed=21)
+    ref = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    ref.forward_backward(z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda())
+    unet = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    calls = []
+
+    def fake_sum(t):
+        calls.append(t.numel())
+        t.mul_(2.0)
+    red = unet.make_reducer(bucket_elems=1 << 21, world_size=2, collective=fake_sum)
+    unet.reducer = red
+    with pytest.raises(RuntimeError):
+        red.finish()                                  # nothing begun yet
+    ts = torch.tensor([1]).long().cuda()
+    ehs_c = ehs.cuda()
+    pred_ref = unet(z_refcat.cuda(), ts, ehs_c.repeat(2, 1, 1), is_target=False).sample
+    pred = unet(z_tag.cuda(), ts, ehs_c, is_target=True).sample
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss = F.mse_loss(pred.float() + pred_ref.float() * 0., target.cuda().float(), reduction="mean")
+    loss.backward()
+    assert red.steps_begun == 1 and red.active
+    red.finish()
+    torch.cuda.synchronize()
+    nb = len(red.ranges)
+    assert nb >= 8 and sorted(red.fired_order) == list(range(nb)) and len(calls) == nb
+    g = unet.parameters()[0].grad
+    assert rel(g, ref.P.grad) < 1e-3 and torch.isfinite(g).all()     # (x2, then x1/2: exact in fp32)
+    with pytest.raises(RuntimeError):
+        red.mark(["conv_out.weight"])                 # a walk that reports to a reducer nobody began
+
+
 def test_captured_training_step_equals_eager(hip_lib):
     """forward_backward_captured: fwd + bwd replayed as one HIP graph == the eager step bit for bit (loss, pred, the whole
     flat gradient), over optimizer steps in between (the derived weight copies are refreshed inside the graph) and with new
@@ -632,3 +705,12 @@ def test_captured_training_step_equals_eager(hip_lib):
         b.optimizer_step(1e-4)
         assert torch.equal(a.P.master, b.P.master)
     assert len(b._graphs) == 1 and b.graph_nodes > 500
+    # a loss-scale change (dynamic scale: every overflow halves it) must REPLACE the captured step, not add a second graph
+    # with its own activation pool; the re-captured step is again the eager step bit for bit
+    for scale in (4.0, 2.0, 4.0):
+        a.loss_scale = b.loss_scale = scale
+        la, pa = a.forward_backward(z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda())
+        lb, pb = b.forward_backward_captured(z_refcat.cuda(), z_tag.cuda(), target.cuda(), 1, ehs.cuda())
+        assert torch.equal(la, lb) and torch.equal(pa, pb) and torch.equal(a.P.grad, b.P.grad), scale
+        assert len(b._graphs) == 1
+    assert b.graph_recaptures == 3

@@ -149,8 +149,9 @@ def test_tiny_episode_against_committed_golden(hip_lib, dt):
         assert d.mean() < (1.0 if dt == torch.float16 else 4.0)
 
 
-@pytest.mark.parametrize("dt,rdt", [(torch.float16, None), (torch.bfloat16, None), (torch.float16, torch.float32)],
-                         ids=["fp16", "bf16", "fp16-fp32stream"])
+@pytest.mark.parametrize("dt,rdt", [(torch.float16, None), (torch.bfloat16, None), (torch.float16, torch.float32),
+                                    (torch.float16, "launcher-default")],
+                         ids=["fp16", "bf16", "fp16-fp32stream", "launcher-default-fp32"])
 def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     """The EXACT BASELINE.json shapes -- configs[1] (512x512, 1-shot, batch 4), configs[2] (512x512, 5-shot,
     batch 2: 6-image in-context latent, 24 576 keys at the 64x64 level) and configs[0]'s resolution (256x256,
@@ -165,7 +166,10 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     fp16-fp32stream: residual_dtype=torch.float32 -- the residual stream summed and stored in fp32 and fed to the convs that
     consume it directly (shortcuts, samplers, proj_out) as a (hi, lo) operand pair; every other MFMA operand fp16.
     Tolerance = north_star's 1e-3; measured 7.55e-4 / 7.42e-4 / 7.72e-4 at the three shapes (what remains is the fp16 rounding
-    of the GroupNorm / LayerNorm outputs that feed the branch convs: profiles/r03_stage_trace_fp16_f32stream.txt)."""
+    of the GroupNorm / LayerNorm outputs that feed the branch convs: profiles/r03_stage_trace_fp16_f32stream.txt).
+    launcher-default-fp32: the reference launcher's DEFAULT call sequence (evaluation_util/main_oss.py:332-369): engines built
+    with no torch_dtype, then `MarigoldPipeline.from_pretrained(..., torch_dtype=torch.float32, unet=unet, vae=vae)` -- the
+    pipeline must land in the fp16 + fp32-stream mode by itself (never silently in bf16) and meet the same 1e-3."""
     from diffews_amd import config, weights
     from diffews_amd.episodes import make_episode_batch
     from diffews_amd.pipeline import MarigoldPipelineRGBLatentNoise
@@ -186,10 +190,22 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     try:
         ou = OracleUNet(**kwf(ucfg)); ou.load_state_dict(usd); ou = ou.eval().cuda()
         ov = OracleVAE(**kwf(vcfg)); ov.load_state_dict(vsd); ov = ov.eval().cuda()
-        pipe = MarigoldPipelineRGBLatentNoise(
-            MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt, residual_dtype=rdt),
-            AutoencoderKL(vcfg, vsd, torch_dtype=dt, residual_dtype=rdt),
-            DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
+        if rdt == "launcher-default":
+            rdt = torch.float32
+            unet, vae = MyUNet2DConditionModel(ucfg, usd), AutoencoderKL(vcfg, vsd)       # E:338-349: no dtype argument
+            assert unet.dtype == torch.bfloat16 and vae.dtype == torch.bfloat16
+            with pytest.warns(UserWarning, match="parity mode"):
+                pipe = MarigoldPipelineRGBLatentNoise.from_pretrained(
+                    None, torch_dtype=torch.float32, unet=unet, vae=vae, controlnet=None, text_embeds=te.cuda(),
+                    image_projector=None, customized_head=None, image_encoder=None,
+                    scheduler=DDIMSchedulerCustomized(**kwf(config.get("scheduler"))))                  # E:355-369
+            assert pipe.unet is unet and unet.dtype == torch.float16 and pipe.vae.dtype == torch.float16
+            assert pipe.vae.residual_dtype == torch.float32 and pipe.requested_dtype == torch.float32
+        else:
+            pipe = MarigoldPipelineRGBLatentNoise(
+                MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt, residual_dtype=rdt),
+                AutoencoderKL(vcfg, vsd, torch_dtype=dt, residual_dtype=rdt),
+                DDIMSchedulerCustomized(**kwf(config.get("scheduler"))), text_embeds=te.cuda())
         assert pipe.residual_dtype == (rdt or dt)
         tol = (1.0e-3 if rdt == torch.float32 else 1.8e-3) if dt == torch.float16 else 1.5e-2
         for b, nshot, res in ((4, 1, 512), (2, 5, 512), (1, 1, 256)):

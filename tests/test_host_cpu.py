@@ -440,6 +440,28 @@ def _rank_overlapped_reduce(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def test_reducer_refuses_to_run_unbegun():
+    """GradBucketReducer: mark() / finish() without begin() raise instead of silently leaving the local gradient in place."""
+    import pytest as _pt
+    from diffews_amd.train import GradBucketReducer, ParamStore
+    buf = torch.zeros(1000 + ParamStore.TAIL)
+    red = GradBucketReducer(buf, {"a": (0, 600), "b": (600, 400)}, bucket_elems=512, world_size=2,
+                            collective=lambda t: t.mul_(2.0))
+    with _pt.raises(RuntimeError):
+        red.mark(["a"])
+    with _pt.raises(RuntimeError):
+        red.finish()
+    buf[:1000] = 1.0
+    buf[1000] = 123.0                   # stale tail value: begin(None) must clear it
+    red.begin(None)
+    red.mark(["b"])
+    red.mark(["a"])
+    avg = red.finish()
+    assert float(avg) == 0.0 and torch.equal(buf[:1000], torch.ones(1000)) and sorted(red.fired_order) == [0, 1, 2][:len(red.ranges)]
+    with _pt.raises(RuntimeError):
+        red.finish()                    # the step is over
+
+
 def test_two_rank_overlapped_gradient_reduce_equals_serial(tmp_path):
     """world_size 2, gloo: GradBucketReducer (buckets issued while the 'backward' still writes the earlier parameters,
     loss in the tail slot of the last range) == allreduce_flat_gradient (serial, after the backward) BIT FOR BIT in fp32;
