@@ -159,7 +159,9 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     the GPU box it can run on the device (MIOpen / rocBLAS fp32 -- used here as the checker only) and finishes
     in seconds where the CPU needs minutes.  Same weights (rounded to the storage dtype) and inputs on both
     sides.  Tile / split-K / GroupNorm-chunk plans depend on the batch, hence the exact batch sizes.
-    Tolerance on the parity tensor z0 (P:769): 1.25 x the measured error, which the per-stage trace
+    Two bounds on the parity tensor z0 (P:769).  INDEPENDENT of the engine: its distance to the fp32 oracle must not exceed
+    1.25 x the distance of the oracle graph run by torch itself in the storage dtype (round 4; at the tiny size this is
+    test_not_worse_than_reference_precision).  Regression guard: 1.25 x the measured error, which the per-stage trace
     (profiles/r02_stage_trace_*.txt) shows to be the floor of ANY 16-bit-storage pipeline:
     every residual-level stage adds exactly one storage rounding (2.9e-4 fp16 / 2.4e-3 bf16) and nothing else;
     measured 1.45e-3 fp16 / 1.18e-2 bf16.
@@ -190,6 +192,8 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
     try:
         ou = OracleUNet(**kwf(ucfg)); ou.load_state_dict(usd); ou = ou.eval().cuda()
         ov = OracleVAE(**kwf(vcfg)); ov.load_state_dict(vsd); ov = ov.eval().cuda()
+        import copy
+        ou_low, ov_low = copy.deepcopy(ou).to(dt), copy.deepcopy(ov).to(dt)
         if rdt == "launcher-default":
             rdt = torch.float32
             unet, vae = MyUNet2DConditionModel(ucfg, usd), AutoencoderKL(vcfg, vsd)       # E:338-349: no dtype argument
@@ -212,9 +216,17 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
             bt = make_episode_batch(b, nshot, res, seed=40 + nshot + b, device="cuda")
             with torch.no_grad():
                 ref = OP.single_infer(ou, ov, bt["support_imgs"], bt["query_img"], bt["support_masks"], te.cuda())
+                # the INDEPENDENT bound: the same oracle graph run by torch with every op in the storage dtype (what the
+                # reference's own `--half_precision` / `.to(dtype)` arithmetic computes) against its fp32 run
+                low = OP.single_infer(ou_low, ov_low, bt["support_imgs"].to(dt), bt["query_img"].to(dt),
+                                      bt["support_masks"].to(dt), te.cuda().to(dt))
             r = pipe.run_episodes(bt["support_imgs"], bt["query_img"], bt["support_masks"], bt["query_mask"])
-            assert rel(r["z0"], ref["z0"]) < tol, (b, nshot, res, rel(r["z0"], ref["z0"]))
-            print(f"[parity] {str(dt):15s} stream {str(rdt or dt):15s} b={b} {nshot}-shot {res}x{res}: z0 rel L2 {rel(r['z0'], ref['z0']):.3e}")
+            e_eng, e_low = rel(r["z0"], ref["z0"]), rel(low["z0"], ref["z0"])
+            print(f"[parity] {str(dt):15s} stream {str(rdt or dt):15s} b={b} {nshot}-shot {res}x{res}: z0 rel L2 {e_eng:.3e}   "
+                  f"(torch in {dt} vs its fp32 run: {e_low:.3e})")
+            assert e_eng < tol, (b, nshot, res, e_eng)
+            assert e_eng <= 1.25 * e_low, (b, nshot, res, e_eng, e_low)
+            del low
             # decoder output in [0, 255] (P:790-795): mean absolute difference in uint8 levels
             seg_ref = ref["seg"].clip(0, 255)
             seg = (r["dec"].clip(-1, 1) * 0.5 + 0.5) * 255
@@ -327,7 +339,23 @@ def _fullsize_train_case(dt, nshot, res, sample_vae, seed):
     loss_o.backward()
     gref = {k: p.grad.detach().cpu() for k, p in ou.named_parameters() if p.grad is not None}
     pred_o, loss_o = pred_o.detach().cpu(), float(loss_o)
-    del ou
+    # ---- the independent bound: the SAME oracle graph under torch.autocast(dt) -- accelerate's mixed_precision (T:1017):
+    # fp32 parameters, matmuls / convs in dt, fp16 with a static loss scale -- against its own fp32 gradient
+    for prm in ou.parameters():
+        prm.grad = None
+    ls = 1.0 if dt == torch.bfloat16 else 1024.0
+    with torch.autocast(device_type="cuda", dtype=dt):
+        ou.clear_attn_bank()
+        ou(zo_refcat, 1, ehs.repeat(nshot, 1, 1), is_target=False)
+        pred_l = ou(zo_tag, 1, ehs, is_target=True)
+        ou.clear_attn_bank()
+    (F.mse_loss(pred_l.float(), target_o.float()) * ls).backward()
+    glow = {k: (p.grad.detach() / ls).cpu() for k, p in ou.named_parameters() if p.grad is not None}
+    keys_l = sorted(gref)
+    out["autocast_flat_rel"] = rel(torch.cat([glow[k].float().reshape(-1) for k in keys_l]),
+                                   torch.cat([gref[k].reshape(-1) for k in keys_l]))
+    out["autocast_pred"] = rel(pred_l.detach().float().cpu(), pred_o)
+    del ou, glow, pred_l
     torch.cuda.empty_cache()
     # ---- engine
     tr = UNetTrainer(ucfg, usd, torch_dtype=dt, loss_scale=1.0 if dt == torch.bfloat16 else 1024.0, dynamic_loss_scale=False)
@@ -368,8 +396,12 @@ def test_fullsize_training_step_against_oracle_autograd(hip_lib, dt, nshot, samp
           f"flat grad rel L2 {r['flat_rel']:.3e}  cos {r['cos']:.6f}" + (f"  latents {r['latents']:.3e}" if sample_vae else ""))
     for e, k, n in r["worst"]:
         print(f"[train-parity]    worst tensor {k:70s} rel L2 {e:.3e}  |g_ref| {n:.3e}")
+    print(f"[train-parity]    torch.autocast({dt}) oracle vs its fp32 run: pred {r['autocast_pred']:.3e}  flat grad rel L2 {r['autocast_flat_rel']:.3e}")
     bf = dt == torch.bfloat16
     assert r["finite"]
+    # independent of the engine's own measured numbers: not worse than 1.25 x torch's mixed-precision arithmetic on this graph
+    assert r["flat_rel"] <= 1.25 * r["autocast_flat_rel"], (r["flat_rel"], r["autocast_flat_rel"])
+    assert r["pred"] <= 1.25 * r["autocast_pred"], (r["pred"], r["autocast_pred"])
     assert r["pred"] < (TRAIN_TOL["pred_bf16"] if bf else TRAIN_TOL["pred_fp16"]), r["pred"]
     assert r["loss"] < (TRAIN_TOL["loss_bf16"] if bf else TRAIN_TOL["loss_fp16"]), r["loss"]
     assert r["flat_rel"] < (TRAIN_TOL["flat_bf16"] if bf else TRAIN_TOL["flat_fp16"]), r["flat_rel"]
