@@ -555,6 +555,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the fp32-stream / configs[2] / configs[4] measurements that follow the headline one (N=1 only)")
+    ap.add_argument("--cfg", action="append", default=[], metavar="FIELD=INT",
+                    help="dfw_config field for this run (A/B of kernel plans, e.g. --cfg k8=0); not a default-changing flag")
     ap.add_argument("--inline", action="store_true",
                     help="run the headline and the secondary measurements in THIS process (default: two child processes, so "
                          "that a failure in a secondary leg cannot take the headline value with it); needed under rocprofv3")
@@ -610,6 +612,9 @@ def main():
         log(f"[bench] rank {rank}/{dist.get_world_size()} on cuda:{dev_index}, backend {dist.get_backend()}")
 
     from diffews_amd.metrics import AverageMeter, fold_class_ids
+    if args.cfg:
+        from diffews_amd import _lib
+        log("[bench] dfw_config:", _lib.configure(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.cfg}))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, blobs = build_pipeline(dtype, tiny=args.tiny)
     if args.residual_dtype == "fp32":

@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
                 ("out_scale", _f32), ("act", _i32), ("geglu", _i32), ("out_mode", _i32), ("splitk", _i32),
                 ("batch", _i32), ("strideA", _i64), ("strideW", _i64), ("strideC", _i64), ("dtype", _i32),
                 ("gn_partial", _vp), ("gn_groups", _i32),
-                ("colscale", _f32), ("colscale_n", _i32), ("residual_f32", _i32)]
+                ("colscale", _f32), ("colscale_n", _i32), ("residual_f32", _i32), ("W_blocked", _vp)]
 
 
 class FsaArgs(C.Structure):
@@ -129,7 +129,7 @@ class AdamWArgs(C.Structure):
 class Config(C.Structure):
     _fields_ = [("conv_patch", _i32), ("big_kernels", _i32), ("big_bm", _i32), ("big_bn", _i32), ("big_bk", _i32),
                 ("gemm_bm", _i32), ("gemm_bn", _i32), ("fsa_key_split", _i32),
-                ("fsa_force_splits", _i32), ("big_min_tiles", _i32)]
+                ("fsa_force_splits", _i32), ("big_min_tiles", _i32), ("k8", _i32)]
 
 
 # every symbol include/diffews_hip.h declares: name -> (restype, argtypes)

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
 
   char* Cb = p.C;
   const u32x4 ra = make_srd(p.A, p.a_bytes);
-  const u32x4 rw = make_srd(p.W, p.w_bytes);
+  // blocked weight copy ([tap][Cin/32][N][32], dfw_gemm_args.W_blocked): a W stage is one contiguous N x 64 B block
+  const bool wblk = p.Wblk != nullptr;
+  const u32x4 rw = make_srd(wblk ? p.Wblk : p.W, p.w_bytes);
 
   auto tile_coords = [&](int t) -> TileC {
     TileC c;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < SW; ++i) {
       const int n = c.n0 + (i * 8 + wave) * 16 + (lane >> 2);
-      w_off[i] = n < p.N ? (uint32_t)(((size_t)n * p.K + kc * 8) * sizeof(T)) : kOOB;
+      w_off[i] = n < p.N ? (uint32_t)(((size_t)n * (wblk ? 32 : p.K) + kc * 8) * sizeof(T)) : kOOB;
     }
   };
   // flattened streams: W step index wl (0 .. total), patch index pl (0 .. my_tiles * cpt)
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
   auto issue_w = [&]() {     // caller guarantees wl < total
     const uint32_t dst = lds0 + (uint32_t)wl_slot * WSTAGE + (uint32_t)wave * 1024u;
     wl_slot = wl_slot + 1 == S ? 0 : wl_slot + 1;
-    const uint32_t koff = (uint32_t)(wl_tap * p.Cin + wl_c * 32) * (uint32_t)sizeof(T);
+    const uint32_t koff = wblk ? (uint32_t)(wl_tap * cpt + wl_c) * (uint32_t)p.N * 64u
+                               : (uint32_t)(wl_tap * p.Cin + wl_c * 32) * (uint32_t)sizeof(T);
 #pragma unroll
     for (int i = 0; i < SW; ++i) dma16(rw, w_off[i] == kOOB ? kOOB : w_off[i] + koff, dst + i * 8192);
     ++wl;

@@ -464,6 +464,7 @@ static int fill_params(const dfw_gemm_args* a, GemmP& p, int& esz) {
   const int rpi = a->rows_per_img > 0 ? a->rows_per_img : (a->taps == 9 ? a->Ho * a->Wo : a->M);
   if ((a->rowbias || a->out_mode == DFW_OUT_NCHW_F32) && rpi <= 0) return DFW_EINVAL;
   p.A = (const char*)a->A; p.W = (const char*)a->W; p.C = (char*)a->C;
+  p.Wblk = a->taps == 9 ? (const char*)a->W_blocked : nullptr;
   p.bias = a->bias; p.rowbias = a->rowbias; p.residual = (const char*)a->residual;
   p.partial = (float*)a->workspace;
   p.a_bytes = (uint32_t)(a->a_elems * esz);
@@ -502,6 +503,10 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
     }
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
+    if (big_bm == 256 && big_bn == 256 && gemm8_eligible(p)) {
+      snprintf(buf, n, "gemm8_kernel<%s,256,256,64,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", a->taps == 9 ? "conv" : "lin");
+      return 0;
+    }
     snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,
              big_bk, a->taps == 9 ? "conv" : "lin");
     return 0;

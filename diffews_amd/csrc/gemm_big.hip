@@ -758,8 +758,10 @@ int launch_gemm_big(const GemmP& p, hipStream_t st) {
     if (bm == 256) return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true, true, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true, true, true>(p, st);
     return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true, true, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true, true, true>(p, st);
   }
-  if (bm == 256 && bn == 256)
+  if (bm == 256 && bn == 256) {
+    if (gemm8_eligible(p)) return launch_gemm8(p, st);      // round 4: the 64-deep K-tile kernel (gemm8.hip)
     return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true, true>(p, st);
+  }
   if (bm == 512)
     return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true, true>(p, st);
   if (bk == 64) return bf ? launch_big<__bf16, 256, 128, 64, 3, 1>(p, st) : launch_big<_Float16, 256, 128, 64, 3, 1>(p, st);

@@ -852,7 +852,7 @@ extern "C" int dfw_graph_memset_nodes(void* graph, int32_t* n_nodes) {
   return c < 0 ? DFW_EINVAL : c;
 }
 
-static const dfw_config kDefaultCfg = {2, 1, 0, 0, 0, 0, 0, 1, 0, 192};
+static const dfw_config kDefaultCfg = {2, 1, 0, 0, 0, 0, 0, 1, 0, 192, 1};
 static dfw_config g_cfg = kDefaultCfg;
 namespace dfw { const dfw_config& cfg() { return g_cfg; } }
 

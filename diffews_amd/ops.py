@@ -131,8 +131,10 @@ def bmm_nt(x, w, out_f32=False, out_scale=1.0):
 
 def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, residual=None,
             out_nchw_f32=False, out_scale=1.0, splitk=None, gn_groups=0, gn_in=None, act=L.ACT_NONE,
-            out_f32=False):
+            out_f32=False, w_blk=None):
     """3x3 conv on NHWC x [B, H, W, Cin] with w packed [Cout, 9*Cin] (ky, kx, cin order).
+    w_blk: optional blocked copy of w (packing.block_conv3x3: [9][Cin/32][Cout][32]) for the kernels that stage W per
+    (tap, 32-channel chunk): their LDS-DMA then fetches whole cache lines (dfw_gemm_args.W_blocked).
     pad = top/left zero padding (bottom/right come from bounds checks: pad=0,stride=2 is the VAE
     encoder's F.pad(0,1,0,1) + conv(stride 2, padding 0)); ups fuses nearest-2x upsampling.
     gn_in = (gamma, beta, groups, eps, silu): the conv's input is GroupNorm(+SiLU) of x, applied by dfw_groupnorm first
@@ -159,6 +161,9 @@ def conv3x3(x, w, cout, bias=None, stride=1, pad=1, ups=False, rowbias=None, res
         out = torch.empty(B, Ho, Wo, cout, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     a = L.GemmArgs()
     a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    if w_blk is not None:
+        assert w_blk.dtype == w.dtype and w_blk.numel() == w.numel() and w_blk.is_contiguous() and Cin % 32 == 0
+        a.W_blocked = w_blk.data_ptr()
     a.bias = _p(_f32(bias, "bias"))
     _rowbias(a, rowbias)
     if residual is not None:

@@ -9,6 +9,15 @@ def pack_conv3x3(w):
     return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
 
 
+def block_conv3x3(wp):
+    """packed [Cout, 9*Cin] -> blocked [9][Cin/32][Cout][32] (dfw_gemm_args.W_blocked): one (tap, 32-channel chunk)
+    stage of the patch conv kernel is one contiguous Cout x 64-byte block."""
+    co, k = wp.shape
+    ci = k // 9
+    assert k == 9 * ci and ci % 32 == 0
+    return wp.view(co, 9, ci // 32, 32).permute(1, 2, 0, 3).contiguous()
+
+
 def pack_conv1x1(w):
     return w.reshape(w.shape[0], w.shape[1]).contiguous()
 

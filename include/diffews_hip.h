@@ -54,6 +54,7 @@ typedef struct {
   int32_t fsa_key_split;     /* 1 (default) split the bank readers' key range when a workspace is passed; 0 never */
   int32_t fsa_force_splits;  /* != 0: this split count for eligible launches (forward and dQ) */
   int32_t big_min_tiles;     /* gemm_big_kernel only for launches with at least this many tiles (default 192 of the 256 CUs) */
+  int32_t k8;                /* 1 (default): gemm8_kernel (64-deep K-tiles, half-tile staging) where gemm_big's 256 x 256 tile was planned; 0: gemm_big */
 } dfw_config;
 int dfw_configure(const dfw_config* cfg);
 void dfw_get_config(dfw_config* out);
@@ -112,6 +113,12 @@ typedef struct {
    * ResnetBlock2D / BasicTransformerBlock / Transformer2DModel is summed and stored in fp32, so the stream
    * is never rounded to 16 bits; only MFMA operands are.  Needs N % 4 == 0 and ldr % 4 == 0. */
   int32_t residual_f32;
+  /* Optional second copy of a conv3x3 weight in the BLOCKED layout [tap][Cin / 32][N][32] (element
+   * ((tap * Cin/32 + c) * N + n) * 32 + k holds W[n][tap * Cin + 32 c + k]): one (tap, 32-channel chunk) W stage of the
+   * patch conv kernel is then ONE contiguous N x 64-byte block, so every LDS-DMA wave-instruction fetches eight whole
+   * 128-byte lines instead of sixteen half lines at a row stride of K elements.  Used by the kernels that stage W per
+   * (tap, chunk) -- conv_patch_kernel; ignored by the others, which read `W`.  NULL: everything reads `W`. */
+  const void* W_blocked;
 } dfw_gemm_args;
 
 int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream);

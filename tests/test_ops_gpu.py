@@ -245,6 +245,105 @@ def test_linear_big_tiles(ops, dtype):
     assert rel(ops.linear(x.cuda(), wp.cuda(), bias=bp.cuda(), geglu=True), a * F.gelu(g)) < TOL[dtype]
 
 
+def _kernel_name(ops, fn):
+    """Name of the GEMM kernel the library plans for the call made inside fn (ops.gemm_hook sees every dfw_gemm)."""
+    names = []
+    ops.gemm_hook = lambda name, flops, e0, e1, shape=None: names.append(name)
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_hook = None
+    return names
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm8_linear(ops, dtype):
+    """gemm8_kernel (round 4: 64-deep K-tiles, half-tile LDS-DMA staging, one instruction stream for both wave groups) on
+    Linear shapes: against the fp32 reference, and BIT-EQUAL to gemm_big_kernel (dfw_config.k8 = 0) -- both accumulate the
+    same 32-deep MFMA steps in the same order.  Ragged M (the buffer bounds check zero-fills the tail rows), several tiles
+    per workgroup (the K-tile stream runs on across tiles), odd and even K-tile counts, bias / residual / row bias /
+    column scale, GEGLU, batched (VAE attention) launches."""
+    from diffews_amd import _lib
+    from diffews_amd.packing import pack_geglu
+    try:
+        for M, N, K in [(49152, 256, 256), (50000, 512, 320), (131072, 256, 448), (70000, 768, 1280)]:
+            x, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+            bias, res = torch.randn(N).cuda(), rnd((M, N), dtype, 3).cuda()
+            rpi = 1000
+            rb = torch.randn((M + rpi - 1) // rpi, N).cuda()
+            kw = dict(bias=bias, residual=res, rowbias=rb, rows_per_img=rpi, out_scale=0.5, colscale=(64, 0.25))
+            _lib.configure(k8=1)
+            assert any(n.startswith("gemm8_kernel") for n in _kernel_name(ops, lambda: ops.linear(x, w, **kw))), (M, N, K)
+            y8 = ops.linear(x, w, **kw)
+            _lib.configure(k8=0)
+            y0 = ops.linear(x, w, **kw)
+            ref = x.float() @ w.float().t() + bias + res.float() + rb.repeat_interleave(rpi, 0)[:M]
+            ref = torch.cat([ref[:, :64] * 0.25, ref[:, 64:] * 0.5], 1)
+            assert rel(y8, ref) < TOL[dtype], (M, N, K)
+            assert torch.equal(y8, y0), (M, N, K, float((y8.float() - y0.float()).abs().max()))
+        # GEGLU (the 64^2-level FF projection shape class)
+        M, C = 24576, 128
+        x = rnd((M, C * 2), dtype, 1).cuda()
+        w, b = rnd((8 * C, 2 * C), dtype, 2, (2 * C) ** -0.5), torch.randn(8 * C) * 0.1
+        a, g = (x.float().cpu() @ w.float().t() + b).chunk(2, dim=-1)
+        wp, bp = pack_geglu(w, b)
+        _lib.configure(k8=1)
+        y8 = ops.linear(x, wp.cuda(), bias=bp.cuda(), geglu=True)
+        _lib.configure(k8=0)
+        y0 = ops.linear(x, wp.cuda(), bias=bp.cuda(), geglu=True)
+        assert rel(y8, a * F.gelu(g)) < TOL[dtype] and torch.equal(y8, y0)
+        # batched: [Bt, M, K] x [Bt, N, K]^T (VAE mid-block attention products)
+        q, k = rnd((3, 4096, 512), dtype, 5).cuda(), rnd((3, 4096, 512), dtype, 6, 512 ** -0.5).cuda()
+        _lib.configure(k8=1)
+        s8 = ops.bmm_nt(q, k)
+        _lib.configure(k8=0)
+        s0 = ops.bmm_nt(q, k)
+        assert rel(s8, torch.bmm(q.float(), k.float().transpose(1, 2))) < TOL[dtype] and torch.equal(s8, s0)
+    finally:
+        _lib.configure()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pad,ups", [(3, 128, 128, 64, 256, 1, 1, True), (4, 256, 256, 128, 256, 2, 0, False),
+                                                          (12, 128, 128, 320, 256, 2, 1, False), (2, 96, 160, 192, 512, 1, 1, True)])
+def test_gemm8_conv_gather(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
+    """gemm8_kernel on the conv3x3 shapes that gather A per tap: fused nearest-2x upsampling (Upsample2D), stride 2 with
+    symmetric (UNet Downsample2D) and asymmetric (VAE encoder: F.pad(0,1,0,1), padding 0) padding; residual, per-image bias,
+    fused GroupNorm statistics; odd K-tile counts (Cin = 320: 45) and several tiles per workgroup.  Against F.conv2d and
+    against gemm_big_kernel (same products, another summation order of the 32-deep steps: fp32 rounding only)."""
+    from diffews_amd import _lib
+    from diffews_amd.packing import pack_conv3x3
+    x = rnd((B, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5)
+    bias, rb = torch.randn(Cout), torch.randn(B, Cout)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    if stride == 2 and pad == 0:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), bias, stride=2)
+    else:
+        ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1)
+    ref = ref + rb[:, :, None, None]
+    res = rnd(tuple(ref.shape), dtype, 3)
+    ref = ref + res.float()
+    xc, wc = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv3x3(w).cuda()
+    kw = dict(bias=bias.cuda(), stride=stride, pad=pad, ups=ups, rowbias=rb.cuda(),
+              residual=res.permute(0, 2, 3, 1).contiguous().cuda(), gn_groups=32)
+    try:
+        _lib.configure(k8=1)
+        names = _kernel_name(ops, lambda: ops.conv3x3(xc, wc, Cout, **kw))
+        assert any(n.startswith("gemm8_kernel") for n in names), names
+        y8 = ops.conv3x3(xc, wc, Cout, **kw)
+        y8b = ops.conv3x3(xc, wc, Cout, **kw)
+        _lib.configure(k8=0)
+        y0 = ops.conv3x3(xc, wc, Cout, **kw)
+    finally:
+        _lib.configure()
+    assert rel(y8.permute(0, 3, 1, 2), ref) < TOL[dtype]
+    assert rel(y8, y0) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert torch.equal(y8, y8b) and torch.equal(y8._gn_stats[0], y8b._gn_stats[0])      # run-to-run: no race in the ring
+    assert y0._gn_stats[1:] == y8._gn_stats[1:] and rel(y8._gn_stats[0], y0._gn_stats[0]) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Cout", [3, 4, 8])
 def test_conv3x3_small_cout_nchw(ops, dtype, Cout):
