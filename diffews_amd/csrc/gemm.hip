@@ -503,8 +503,8 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
     }
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) {
-    if (big_bm == 256 && big_bn == 256 && gemm8_eligible(p)) {
-      snprintf(buf, n, "gemm8_kernel<%s,256,256,64,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", a->taps == 9 ? "conv" : "lin");
+    if (big_bm == 256 && (big_bn == 256 || big_bn == 128) && gemm8_eligible(p, big_bn)) {
+      snprintf(buf, n, "gemm8_kernel<%s,256,%d,64,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bn, a->taps == 9 ? "conv" : "lin");
       return 0;
     }
     snprintf(buf, n, "gemm_big_kernel<%s,%d,%d,%d,%s>", a->dtype == DFW_BF16 ? "bf16" : "f16", big_bm, big_bn,

@@ -28,13 +28,20 @@
 
 namespace dfw {
 
-template <typename T, bool CONV>
+// BN = 256: wave grid 2 (M) x 4 (N), wave tile 128 x 64 (the scheme above).  BN = 128: wave grid 4 x 2, wave tile 64 x 64, ONE W
+// half-tile per K-tile, 16-MFMA phases; the wave groups (wave >> 2) still own the A half-tiles 0 / 1.
+template <typename T, bool CONV, int BN>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
-  constexpr int BM = 256, BN = 256, HT = 16384, STG = 131072;
+  constexpr int BM = 256, HT = 16384;
+  constexpr int WH = BN / 128;                          // W half-tiles per K-tile
+  constexpr int WGN = BN / 64, WGM = 8 / WGN;           // wave grid
+  constexpr int WTM = BM / WGM, MB6 = WTM / 16, MH = MB6 / 2;   // wave tile rows, its 16-row blocks, blocks per quadrant
+  constexpr int STG = (2 + WH) * 32768;                 // epilogue staging behind the half-tile slots
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave >> 2;                             // wave group = A half-tile
+  const int wm = wave / WGN, wc = wave % WGN;           // position in the wave grid (wm / (WGM / 2) == wr)
   const uint32_t lds0 = lds_addr(smem);
 
   // ---- persistent tile walk (gemm_big.hip's XCD-contiguous order)
@@ -138,12 +145,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
     }
     a_advance();
   };
-  // W cursor (N % 256 == 0: every row of a W tile exists)
+  // W cursor (BN = 256: N % 256 == 0, every row of a W tile exists; BN = 128: rows beyond N are zero-filled)
   int w_kt = 0, w_ti = 0;
   bool w_live = true;
   uint32_t w_v0 = 0;
+  int w_n = 0;
   auto w_setup = [&](const TileC& c) {
-    w_v0 = (uint32_t)(((size_t)(c.n0 + wave * 8 + lrow) * p.K + kc * 8) * sizeof(T));
+    w_n = c.n0 + wave * 8 + lrow;
+    w_v0 = (uint32_t)(((size_t)w_n * p.K + kc * 8) * sizeof(T));
   };
   auto issue_w = [&](int buf) __attribute__((always_inline)) {
     uint32_t koff = (uint32_t)w_kt * 128u;
@@ -152,12 +161,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
       koff = (uint32_t)(tap * p.Cin + cc * 64) * (uint32_t)sizeof(T);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < WH; ++h) {
       const uint32_t dst = lds0 + (uint32_t)((2 + h) * 32768 + buf * HT) + (uint32_t)wave * 1024u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const uint32_t off = w_v0 + (uint32_t)(h * 128 + j * 64) * (uint32_t)p.K * (uint32_t)sizeof(T) + koff;
-        dma16(rw, w_live ? off : kOOB, dst + j * 8192);
+        bool ok = w_live;
+        if constexpr (BN == 128) ok = ok && (w_n + j * 64 < p.N);
+        dma16(rw, ok ? off : kOOB, dst + j * 8192);
       }
     }
     if (++w_kt == nkt) {
@@ -173,17 +184,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
   {
     const int l15 = lane & 15, l4 = lane >> 4;
     const uint32_t fb = (uint32_t)(l15 * 128 + ((l4 ^ (l15 >> 1)) << 4));
-    ab0 = (uint32_t)(wr * 32768) + fb;
+    ab0 = (uint32_t)(wr * 32768 + (wm % (WGM / 2)) * WTM * 128) + fb;
     ab1 = ab0 ^ 64u;
     wb0 = (uint32_t)((2 + (wc >> 1)) * 32768 + (wc & 1) * 64 * 128) + fb;
     wb1 = wb0 ^ 64u;
   }
 
-  f32x4 acc6[8][4];
-  typename Tr<T>::v8 fa[4][2], fw0[2][2], fw1[2][2];
+  f32x4 acc6[MB6][4];
+  typename Tr<T>::v8 fa[MH][2], fw0[2][2], fw1[2][2];
   auto zero6 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MB6; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc6[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
@@ -199,9 +210,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
   };
   auto read_a = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i][0] = as_v8<T>(*(const i32x4*)(smem + ab0 + (64 * s + 16 * i) * 128));
-      fa[i][1] = as_v8<T>(*(const i32x4*)(smem + ab1 + (64 * s + 16 * i) * 128));
+    for (int i = 0; i < MH; ++i) {
+      fa[i][0] = as_v8<T>(*(const i32x4*)(smem + ab0 + (16 * MH * s + 16 * i) * 128));
+      fa[i][1] = as_v8<T>(*(const i32x4*)(smem + ab1 + (16 * MH * s + 16 * i) * 128));
     }
   };
   auto read_w = [&](typename Tr<T>::v8 (&fw)[2][2], int u) __attribute__((always_inline)) {
@@ -215,17 +226,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MH; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc6[4 * s + i][2 * u + j] = Tr<T>::mfma16(fw[j][kh], fa[i][kh], acc6[4 * s + i][2 * u + j]);
+          acc6[MH * s + i][2 * u + j] = Tr<T>::mfma16(fw[j][kh], fa[i][kh], acc6[MH * s + i][2 * u + j]);
   };
 
   // ---- staged epilogue: gemm_big.hip's 16x16x32 epilogue (32 tile rows per round through the wave's 4 KiB: row r,
   // 16-byte chunk c at ((c ^ (r & 7)) << 4) of a 128-byte line; statistics of the STORED values; whole-line stores)
   auto epilogue6 = [&](const TileC& c, char* stg, int tile_id) {
-    constexpr int MB6 = 8, NB6 = 4, WTM = 128, WGM = 2;
-    if (c.n0 + wc * 64 >= p.N) return;
+    constexpr int NB6 = 4;
+    if (c.n0 + wc * 64 >= p.N) return;      // ragged N (a multiple of 64 on 128-wide tiles): this wave multiplied zero-filled W rows
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
       if (p.geglu) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int m = row_to_m(c, wr * WTM + i * 32 + h * 16 + l15);
+          const int m = row_to_m(c, wm * WTM + i * 32 + h * 16 + l15);
           if (m >= p.M) continue;
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb) {     // channel blocks 0,1 = value, 2,3 = gate (packing.pack_geglu)
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
       i32x2 res[2][NB6];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int m = row_to_m(c, wr * WTM + i * 32 + h * 16 + l15);
+        const int m = row_to_m(c, wm * WTM + i * 32 + h * 16 + l15);
         int img_ = c.img;
         if constexpr (!CONV) img_ = (p.rowbias && m < p.M) ? m / p.rows_per_img : 0;
 #pragma unroll
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = (lane >> 3) + 8 * t;
-        const int m2 = row_to_m(c, wr * WTM + i * 32 + r);
+        const int m2 = row_to_m(c, wm * WTM + i * 32 + r);
         const i32x4 val = *(const i32x4*)(stg + r * 128 + ((c16 ^ (r & 7)) << 4));
         if (m2 < p.M)
           *(i32x4*)(Cb + ((size_t)m2 * p.ldc + c.n0 + wc * 64 + c16 * 8) * sizeof(T)) = val;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
       const int cp = lane & 31;
       if (lane < 32 && (cp & (ppg - 1)) == 0) {
         const int tm = tile_id / p.ntn;
-        const int chunk = (tm - c.img * p.tpi) * WGM + wr;
+        const int chunk = (tm - c.img * p.tpi) * WGM + wm;
         const int grp = (c.n0 + wc * 64 + 2 * cp) / cpg;
         float* o2 = p.gn_partial + (((size_t)c.img * p.gn_chunks + chunk) * p.gn_groups + grp) * 2;
         o2[0] = s2;
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
   issue_w(0);
   issue_a(0);
   issue_w(1);
-  wait_vm<4>();
+  wait_vm<2 * WH>();
   bar();
   if (wr == 1) bar();                       // the stagger: wave group 1 runs one barrier behind group 0
   zero6();
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
     // PB
     read_a(1);
     issue_w(buf);
-    wait_vm<4>();
+    wait_vm<2 * WH>();
     lgkm0();
     bar();
     __builtin_amdgcn_s_setprio(1);
@@ -387,11 +398,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
   wait_vm<0>();                              // the cursors' tail issues (zero-filled, into slots nobody reads) drain before exit
 }
 
-template <typename T>
+template <typename T, int BN>
 static int launch8(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.ntm = (p.M + 255) / 256;
-  q.ntn = p.N / 256;
+  q.ntn = (p.N + BN - 1) / BN;
   q.gn_chunks = p.gn_partial ? gemm_big_gn_chunks(p) : 0;
   if (q.gn_chunks == 0) q.gn_partial = nullptr;
   q.tw = 0; q.tw_log2 = 0; q.tpr = 0; q.tpi = 0;
@@ -400,18 +411,18 @@ static int launch8(const GemmP& p, hipStream_t st) {
     q.tpr = p.Wo / 16;
     q.tpi = q.tpr * (p.Ho / 16);
   }
-  constexpr size_t lds = 131072 + 32768;
+  constexpr size_t lds = (size_t)(2 + BN / 128) * 32768 + 32768;
   const int zdim = p.batch > 1 ? p.batch : 1;
   int nwg = q.ntm * q.ntn;
   if (nwg > 256) nwg = 256;
   nwg = (nwg + 7) & ~7;
   dim3 grid(nwg, zdim);
   if (p.taps == 1) {
-    auto kfn = gemm8_kernel<T, false>;
+    auto kfn = gemm8_kernel<T, false, BN>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   } else {
-    auto kfn = gemm8_kernel<T, true>;
+    auto kfn = gemm8_kernel<T, true, BN>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
   }
@@ -421,14 +432,16 @@ static int launch8(const GemmP& p, hipStream_t st) {
 
 // Shapes of gemm_big's 256 x 256 configuration with a 64-deep K walk: storage-dtype output, N % 256 == 0, K % 64 == 0 (convs:
 // Cin % 64 == 0), at least four K-tiles.
-bool gemm8_eligible(const GemmP& p) {
+bool gemm8_eligible(const GemmP& p, int bn) {
   if (!cfg().k8 || p.out_mode != DFW_OUT_T || p.res_f32) return false;
-  if ((p.N % 256) != 0 || (p.K % 64) != 0 || (p.Cin % 64) != 0 || p.K / 64 < 4) return false;
-  return true;
+  if ((p.K % 64) != 0 || (p.Cin % 64) != 0 || p.K / 64 < 2) return false;
+  if (bn == 256) return (p.N % 256) == 0;
+  return bn == 128 && (p.N % 64) == 0 && cfg().k8 >= 2;
 }
 
-int launch_gemm8(const GemmP& p, hipStream_t st) {
-  return p.dtype_bf16 ? launch8<__bf16>(p, st) : launch8<_Float16>(p, st);
+int launch_gemm8(const GemmP& p, hipStream_t st, int bn) {
+  if (bn == 256) return p.dtype_bf16 ? launch8<__bf16, 256>(p, st) : launch8<_Float16, 256>(p, st);
+  return p.dtype_bf16 ? launch8<__bf16, 128>(p, st) : launch8<_Float16, 128>(p, st);
 }
 
 }  // namespace dfw

@@ -728,6 +728,10 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
         return true;
       }
     }
+    if (list == narrow && cfg().k8 >= 3 && big_cfg_ok(p, narrow[1]) && gemm8_eligible(p, 128)) {
+      bm = narrow[1].bm; bn = narrow[1].bn; bk = narrow[1].bk;
+      return true;
+    }
     for (int i = 0; i < 3; ++i)
       if (big_cfg_ok(p, list[i])) {
         bm = list[i].bm; bn = list[i].bn; bk = list[i].bk;
@@ -759,11 +763,12 @@ int launch_gemm_big(const GemmP& p, hipStream_t st) {
     return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true, true, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true, true, true>(p, st);
   }
   if (bm == 256 && bn == 256) {
-    if (gemm8_eligible(p)) return launch_gemm8(p, st);      // round 4: the 64-deep K-tile kernel (gemm8.hip)
+    if (gemm8_eligible(p, 256)) return launch_gemm8(p, st, 256);      // round 4: the 64-deep K-tile kernel (gemm8.hip)
     return bf ? launch_big<__bf16, 256, 256, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 256, 256, 32, 4, 1, true, true>(p, st);
   }
   if (bm == 512)
     return bf ? launch_big<__bf16, 512, 128, 32, 4, 1, true, true>(p, st) : launch_big<_Float16, 512, 128, 32, 4, 1, true, true>(p, st);
+  if (bm == 256 && bn == 128 && gemm8_eligible(p, 128)) return launch_gemm8(p, st, 128);   // dfw_config.k8 >= 2
   if (bk == 64) return bf ? launch_big<__bf16, 256, 128, 64, 3, 1>(p, st) : launch_big<_Float16, 256, 128, 64, 3, 1>(p, st);
   return bf ? launch_big<__bf16, 256, 128, 32, 4, 1>(p, st) : launch_big<_Float16, 256, 128, 32, 4, 1>(p, st);
 }

@@ -197,8 +197,8 @@ struct TileC {
 int launch_gemm_big(const GemmP& p, hipStream_t st);  // gemm_big.hip
 bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk);
 int gemm_big_gn_chunks(const GemmP& p);   // > 0: the planned big kernel can emit GroupNorm partials
-int launch_gemm8(const GemmP& p, hipStream_t st);       // gemm8.hip
-bool gemm8_eligible(const GemmP& p);
+int launch_gemm8(const GemmP& p, hipStream_t st, int bn);   // gemm8.hip
+bool gemm8_eligible(const GemmP& p, int bn);
 int launch_conv_patch(const GemmP& p, hipStream_t st);  // conv_patch.hip
 bool conv_patch_eligible(const GemmP& p, int& bm, int& bn);
 int conv_patch_gn_chunks(const GemmP& p);

@@ -54,7 +54,8 @@ typedef struct {
   int32_t fsa_key_split;     /* 1 (default) split the bank readers' key range when a workspace is passed; 0 never */
   int32_t fsa_force_splits;  /* != 0: this split count for eligible launches (forward and dQ) */
   int32_t big_min_tiles;     /* gemm_big_kernel only for launches with at least this many tiles (default 192 of the 256 CUs) */
-  int32_t k8;                /* 1 (default): gemm8_kernel (64-deep K-tiles, half-tile staging) where gemm_big's 256 x 256 tile was planned; 0: gemm_big */
+  int32_t k8;                /* gemm8_kernel (64-deep K-tiles, half-tile staging): 0 never; 1 where gemm_big's 256 x 256 tile was planned;
+                                2 also its 256 x 128 tiles; 3 also 256 x 128 in place of gemm_big's 512 x 128 tile */
 } dfw_config;
 int dfw_configure(const dfw_config* cfg);
 void dfw_get_config(dfw_config* out);

@@ -267,13 +267,16 @@ def test_gemm8_linear(ops, dtype):
     from diffews_amd import _lib
     from diffews_amd.packing import pack_geglu
     try:
-        for M, N, K in [(49152, 256, 256), (50000, 512, 320), (131072, 256, 448), (70000, 768, 1280)]:
+        # N % 256 == 0: the 256 x 256 tile; N = 384 / 960 / 128: the 256 x 128 tile (dfw_config.k8 = 3 plans it where gemm_big's
+        # 512 x 128 or 256 x 128 tiles were planned; 960 = a half-empty last column tile, K = 128 = two K-tiles per tile)
+        for M, N, K in [(49152, 256, 256), (50000, 512, 320), (131072, 256, 448), (70000, 768, 1280), (49152, 384, 320),
+                        (33000, 960, 320), (200000, 128, 256), (786432, 256, 128)]:
             x, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
             bias, res = torch.randn(N).cuda(), rnd((M, N), dtype, 3).cuda()
             rpi = 1000
             rb = torch.randn((M + rpi - 1) // rpi, N).cuda()
             kw = dict(bias=bias, residual=res, rowbias=rb, rows_per_img=rpi, out_scale=0.5, colscale=(64, 0.25))
-            _lib.configure(k8=1)
+            _lib.configure(k8=3)
             assert any(n.startswith("gemm8_kernel") for n in _kernel_name(ops, lambda: ops.linear(x, w, **kw))), (M, N, K)
             y8 = ops.linear(x, w, **kw)
             _lib.configure(k8=0)
@@ -288,14 +291,14 @@ def test_gemm8_linear(ops, dtype):
         w, b = rnd((8 * C, 2 * C), dtype, 2, (2 * C) ** -0.5), torch.randn(8 * C) * 0.1
         a, g = (x.float().cpu() @ w.float().t() + b).chunk(2, dim=-1)
         wp, bp = pack_geglu(w, b)
-        _lib.configure(k8=1)
+        _lib.configure(k8=3)
         y8 = ops.linear(x, wp.cuda(), bias=bp.cuda(), geglu=True)
         _lib.configure(k8=0)
         y0 = ops.linear(x, wp.cuda(), bias=bp.cuda(), geglu=True)
         assert rel(y8, a * F.gelu(g)) < TOL[dtype] and torch.equal(y8, y0)
         # batched: [Bt, M, K] x [Bt, N, K]^T (VAE mid-block attention products)
         q, k = rnd((3, 4096, 512), dtype, 5).cuda(), rnd((3, 4096, 512), dtype, 6, 512 ** -0.5).cuda()
-        _lib.configure(k8=1)
+        _lib.configure(k8=3)
         s8 = ops.bmm_nt(q, k)
         _lib.configure(k8=0)
         s0 = ops.bmm_nt(q, k)
@@ -306,7 +309,8 @@ def test_gemm8_linear(ops, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pad,ups", [(3, 128, 128, 64, 256, 1, 1, True), (4, 256, 256, 128, 256, 2, 0, False),
-                                                          (12, 128, 128, 320, 256, 2, 1, False), (2, 96, 160, 192, 512, 1, 1, True)])
+                                                          (12, 128, 128, 320, 256, 2, 1, False), (2, 96, 160, 192, 512, 1, 1, True),
+                                                          (4, 256, 256, 128, 128, 2, 0, False), (3, 64, 64, 640, 128, 1, 1, True), (3, 64, 64, 320, 384, 1, 1, True)])
 def test_gemm8_conv_gather(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
     """gemm8_kernel on the conv3x3 shapes that gather A per tap: fused nearest-2x upsampling (Upsample2D), stride 2 with
     symmetric (UNet Downsample2D) and asymmetric (VAE encoder: F.pad(0,1,0,1), padding 0) padding; residual, per-image bias,
@@ -329,7 +333,7 @@ def test_gemm8_conv_gather(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
     kw = dict(bias=bias.cuda(), stride=stride, pad=pad, ups=ups, rowbias=rb.cuda(),
               residual=res.permute(0, 2, 3, 1).contiguous().cuda(), gn_groups=32)
     try:
-        _lib.configure(k8=1)
+        _lib.configure(k8=3)
         names = _kernel_name(ops, lambda: ops.conv3x3(xc, wc, Cout, **kw))
         assert any(n.startswith("gemm8_kernel") for n in names), names
         y8 = ops.conv3x3(xc, wc, Cout, **kw)
@@ -340,8 +344,10 @@ def test_gemm8_conv_gather(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
         _lib.configure()
     assert rel(y8.permute(0, 3, 1, 2), ref) < TOL[dtype]
     assert rel(y8, y0) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
-    assert torch.equal(y8, y8b) and torch.equal(y8._gn_stats[0], y8b._gn_stats[0])      # run-to-run: no race in the ring
-    assert y0._gn_stats[1:] == y8._gn_stats[1:] and rel(y8._gn_stats[0], y0._gn_stats[0]) < 1e-3
+    assert torch.equal(y8, y8b)                                           # run-to-run: no race in the ring
+    if Cout % 32 == 0 and ((Cout // 32) & (Cout // 32 - 1)) == 0:        # channel groups that tile the 64-column wave tiles
+        assert torch.equal(y8._gn_stats[0], y8b._gn_stats[0])
+        assert y0._gn_stats[1:] == y8._gn_stats[1:] and rel(y8._gn_stats[0], y0._gn_stats[0]) < 1e-3
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
