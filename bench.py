@@ -449,11 +449,20 @@ def train_main(args):
     # DDP's gradient all-reduce (T:1226-1228, T:1391), overlapped: the flat gradient's buckets are reduced from a side
     # stream while the backward of the earlier layers still runs; the loss rides in the last range (T:1387)
     comm_dt = torch.bfloat16 if args.grad_comm_dtype == "bf16" else torch.float32
-    red = tr.make_reducer(comm_dtype=comm_dt) if world > 1 else None
+    red = tr.make_reducer(bucket_elems=args.grad_bucket_mb * 250_000, comm_dtype=comm_dt) if (world > 1 or args.segmented) else None
 
-    use_graph = world == 1 and not args.no_graph      # fwd + bwd as one HIP graph; the overlapped all-reduce needs the eager walk
+    # one GPU: fwd + bwd as ONE HIP graph.  N GPUs: the same work as a chain of graphs cut where a gradient bucket becomes final,
+    # the reducer issuing that bucket's all-reduce between two segments (round 4; --no-graph: the eager walk of rounds 2-3)
+    use_graph = world == 1 and not args.no_graph and not args.segmented
+    use_seg = (world > 1 or args.segmented) and not args.no_graph
 
     def train(lat):
+        if use_seg and ops_hook_off() and red is not None:
+            loss, _ = tr.forward_backward_segmented(lat[0], lat[1], lat[2], 1, ehs, red)   # rank-averaged loss, streams joined
+            tr.optimizer_step(poly_lr(1e-5, state["step"], 10000), max_grad_norm=1.0)
+            state["step"] += 1
+            state["loss"] = loss
+            return
         if use_graph and ops_hook_off():
             loss, _ = tr.forward_backward_captured(lat[0], lat[1], lat[2], 1, ehs)      # T:1367-1391, one graph replay
         else:
@@ -530,7 +539,9 @@ def train_main(args):
                            "parallelism": f"data-parallel x{world}, flat gradient all-reduce in 216 MB buckets ({args.grad_comm_dtype} on the wire) "
                                           "issued from a side stream during the backward, loss in the last bucket",
                            "optimizer": "clip_grad_norm_(1.0) + AdamW, fp32 master",
-                           "hip_graph": "UNet forward + backward (UNetTrainer.forward_backward_captured)" if use_graph else False,
+                           "hip_graph": ("UNet forward + backward (UNetTrainer.forward_backward_captured)" if use_graph else
+                                         ("UNet forward + backward as a chain of graphs cut at the gradient buckets "
+                                          "(UNetTrainer.forward_backward_segmented)" if use_seg else False)),
                            "vae_encode": "one batch of 2s+2 images per step" + (", next batch's encodes on a side stream during the UNet step" if prefetch else "")},
                 "roofline": roof, "cpu_baseline": None}
         print(json.dumps(line), flush=True)
@@ -567,6 +578,10 @@ def main():
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="--train, N > 1: wire format of the gradient all-reduce (fp32 = DDP's; bf16 halves the xGMI bytes)")
     ap.add_argument("--prefetch", action="store_true", help="--train: encode the next batch on a side stream beside the step")
+    ap.add_argument("--grad-bucket-mb", type=int, default=216, help="--train: size of a gradient all-reduce bucket in MB (fp32)")
+    ap.add_argument("--segmented", action="store_true",
+                    help="--train on ONE GPU: run the multi-GPU form of the step (forward + backward as a chain of HIP graphs cut at "
+                         "the gradient-bucket boundaries, the reducer firing between segments) to measure it against the monolithic graph")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[4] instead of the headline metric: training step (VAE-encode with sampling, UNet "
                          "fwd+bwd over a 7-shot episode per GPU, gradient all-reduce over the ranks, clip + AdamW)")

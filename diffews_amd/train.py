@@ -703,9 +703,16 @@ class UNetTrainer:
         tape, hn, h, w, c0, oc = c["tape"], c["hn"], c["h"], c["w"], c["c0"], c["oc"]
         # bias / time-projection column sums are queued and issued in batches (ob.ColsumQueue): with a reducer, before every
         # readiness report (a gradient is final only once its launch is in the stream); otherwise twice per walk
-        def _note():
-            self._cs.flush()
-            reducer.mark(P.pop_written())
+        # (round 4: the queue is flushed only when the names reported so far would COMPLETE a bucket -- flushing after every
+        # closure issued the ~190 column sums one by one and cost the reducer path 1.5 ms per step against the fused one)
+        pend = []
+
+        def _note(final=False):
+            pend.extend(P.pop_written())
+            if pend and (final or reducer.would_fire(pend)):
+                self._cs.flush()
+                reducer.mark(list(pend))
+                pend.clear()
         note = _note if reducer is not None else None
         # conv_out backward: weight / bias gradients in place (padded to 8 rows), data gradient by the direct conv
         ob.gemm_tn(c["dpred"], hn, taps=9, geom=(h, w, h, w, 1, 1, 0), out=P.g("conv_out.weight").view(1, 8, 9, c0), accumulate=P.acc("conv_out.weight"), scale=gs)
@@ -720,7 +727,7 @@ class UNetTrainer:
         self._cs.flush()
         P.finish_step()
         if note:
-            note()
+            note(final=True)
         self._freeze_derived()
 
     def forward_backward(self, z_refcat, z_tag, target, timestep, ehs, zero_grad=True, reducer=None):
@@ -792,6 +799,59 @@ class UNetTrainer:
                 dst.copy_(src, non_blocking=True)
         graph.replay()
         return loss, pred
+
+    def forward_backward_segmented(self, z_refcat, z_tag, target, timestep, ehs, reducer):
+        """Multi-GPU form of forward_backward_captured (round 4): forward + backward replayed as a CHAIN of HIP graphs cut
+        where a gradient bucket becomes final, so that the overlapped all-reduce keeps its place -- after each segment the
+        reducer issues that segment's buckets from its comm stream while the next segment already runs.  The eager walk
+        needed ~2 200 host-side launches per step for the sake of those readiness marks; here the host issues one graph
+        launch per segment (17 for the 866 M-parameter UNet at the default 216 MB buckets).  Captured on first use per input
+        shape (and per loss scale, like the monolithic graph); returns (rank-averaged loss [1], pred)."""
+        self._resolve_overflow()
+        ins = [t.to(self.device, torch.float32).contiguous() for t in (z_refcat, z_tag, target)] + [ehs.to(self.device).contiguous()]
+        key = ("segmented", tuple(tuple(t.shape) for t in ins), float(timestep), id(reducer))
+        ent = self._graphs.get(key)
+        if ent is not None and ent[4] != self.loss_scale:
+            del self._graphs[key]
+            for g, _ in ent[0]:
+                g.reset()
+            ent = None
+            self.graph_recaptures += 1
+            torch.cuda.empty_cache()
+        if ent is None:
+            static = [t.clone() for t in ins]
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):                    # lazy derived-weight copies, then the frozen batched re-layout table
+                    self.forward_backward(static[0], static[1], static[2], float(timestep), static[3])
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self._derived_version = -2                # the refresh of the derived weight copies belongs to the first segment
+            dyn, self.dynamic_loss_scale = self.dynamic_loss_scale, False
+            rec = _SegmentRecorder(reducer, torch.cuda.graph_pool_handle())
+            try:
+                with torch.cuda.stream(side):
+                    rec._open()
+                    loss, pred = self.forward_backward(static[0], static[1], static[2], float(timestep), static[3], reducer=rec)
+                    rec.finish()
+            finally:
+                self.dynamic_loss_scale = dyn
+            cur.wait_stream(side)
+            from .pipeline import _assert_no_memset_nodes
+            self.graph_nodes = 0
+            for g, _ in rec.segments:
+                self.graph_nodes += _assert_no_memset_nodes(g)
+                g.instantiate()
+            ent = (rec.segments, static, loss, pred, self.loss_scale)
+            self._graphs[key] = ent
+        segments, static, loss, pred, _ = ent
+        for dst, src in zip(static, ins):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        avg = replay_segments(segments, reducer)
+        return avg, pred
 
     # ------------------------------------------------------------------ the reference's call surface (T:1374-1396)
     def __call__(self, *a, **k):
@@ -1026,6 +1086,66 @@ def allreduce_flat_gradient(flat_grad, world_size=None, bucket_elems=54_000_000,
     return flat_grad
 
 
+class _SegmentRecorder:
+    """Stands in for a GradBucketReducer while UNetTrainer.forward_backward is CAPTURED: same begin / mark / finish calls, but
+    instead of issuing a bucket's collective when its last writer is in the stream it ENDS the HIP graph being captured
+    there and begins the next one.  Result: `segments` = [(graph, [bucket, ...]), ...] -- replaying graph i and then firing
+    its buckets reproduces the eager overlapped step launch for launch (replay_segments)."""
+
+    def __init__(self, reducer, pool):
+        self.red, self.pool = reducer, pool
+        self.segments, self.cur = [], None
+
+    def _open(self):
+        self.cur = torch.cuda.CUDAGraph(keep_graph=True)
+        self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def _close(self, buckets):
+        self.cur.capture_end()
+        self.segments.append((self.cur, list(buckets)))
+        self.cur = None
+
+    def begin(self, loss=None):
+        r = self.red
+        r.reset_state()
+        slot = r.buf[r.loss_slot:r.loss_slot + 1]
+        if loss is None:
+            raise ValueError("the segmented step carries the loss in the last bucket: begin(loss)")
+        slot.copy_(loss.reshape(1).to(r.buf.dtype))          # captured in the first segment (a copy kernel, not a memset)
+
+    def would_fire(self, names):
+        return self.red.would_fire(names)
+
+    def mark(self, names):
+        ready = self.red.ready_after(names)
+        if ready:
+            for b in ready:
+                self.red.fired[b] = True
+            self._close(ready)
+            self._open()
+
+    def finish(self):
+        rest = [b for b in range(len(self.red.ranges) - 1, -1, -1) if not self.red.fired[b]]
+        for b in rest:
+            self.red.fired[b] = True
+        self._close(rest)
+        self.red.active = False
+
+
+def replay_segments(segments, reducer):
+    """One training micro-step as a chain of captured segments: replay segment i (its kernels enter the compute stream), then
+    issue the all-reduce of the gradient buckets whose last writer was in it -- from the reducer's comm stream, behind an
+    event, while the compute stream goes on with segment i + 1.  Same buckets, same order, same arithmetic as the eager
+    overlapped step and as the serial allreduce_flat_gradient (bit-identical in fp32).  Returns reducer.finish()'s loss."""
+    reducer.reset_state()
+    for graph, buckets in segments:
+        graph.replay()
+        for b in buckets:
+            if not reducer.fired[b]:
+                reducer._fire(b)
+    return reducer.finish()
+
+
 class GradBucketReducer:
     """DDP's overlapped gradient all-reduce (T:1226-1228, T:1391) for the flat gradient buffer.
 
@@ -1066,13 +1186,38 @@ class GradBucketReducer:
         self.active = False
         self.steps_begun = 0                          # begin() calls so far (tests / launch-loop sanity checks)
 
-    def begin(self, loss=None):
-        """Start of a backward walk.  loss: the scalar to average with the last bucket (None: the slot carries 0)."""
+    def reset_state(self):
+        """Host-side bookkeeping of begin() alone (no device work): the segmented graph replay re-arms the reducer with it,
+        the loss slot having been written by the first captured segment."""
         self.left = [set(s) for s in self.need]
         self.fired = [False] * len(self.ranges)
         self.fired_order = []
         self.active = True
         self.steps_begun += 1
+
+    def would_fire(self, names):
+        """True if reporting `names` now would complete at least one bucket (nothing is changed)."""
+        ns = set(names)
+        for name in names:
+            for b in self.of.get(name, ()):
+                if not self.fired[b] and self.left[b] <= ns:
+                    return True
+        return False
+
+    def ready_after(self, names):
+        """Buckets (indices, in firing order) that become complete once `names` are final -- mark() without the firing;
+        the segment recorder cuts the captured step there."""
+        out = []
+        for name in names:
+            for b in self.of.get(name, ()):
+                self.left[b].discard(name)
+                if not self.left[b] and not self.fired[b] and b not in out:
+                    out.append(b)
+        return out
+
+    def begin(self, loss=None):
+        """Start of a backward walk.  loss: the scalar to average with the last bucket (None: the slot carries 0)."""
+        self.reset_state()
         slot = self.buf[self.loss_slot:self.loss_slot + 1]
         if loss is not None:                          # before any bucket can fire: the loss is known ahead of the backward
             slot.copy_(loss.reshape(1).to(self.buf.dtype))

@@ -686,6 +686,37 @@ def test_autograd_surface_reduces_every_bucket_with_attached_reducer(hip_lib):
         red.mark(["conv_out.weight"])                 # a walk that reports to a reducer nobody began
 
 
+def test_segmented_training_step_equals_eager_overlapped(hip_lib):
+    """forward_backward_segmented (multi-GPU form of the captured step, round 4): forward + backward as a CHAIN of HIP graphs cut
+    where a gradient bucket becomes final, the reducer firing between segments == the eager overlapped step bit for bit -- loss,
+    prediction, the whole reduced flat gradient, the firing order -- over optimizer steps and new inputs; every bucket's collective
+    sees its final values (the injected collective doubles what it is given: a 2-rank SUM of equal gradients); no memset node."""
+    from diffews_amd.train import UNetTrainer
+    dtype = torch.bfloat16
+    ucfg, usd, _, z_refcat, z_tag, target, ehs = _train_setup(dtype, 1, 2, seed=23)
+    a = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    b = UNetTrainer(ucfg, usd, torch_dtype=dtype)
+    ra = a.make_reducer(bucket_elems=1 << 21, world_size=2, collective=lambda t: t.mul_(2.0))
+    rb = b.make_reducer(bucket_elems=1 << 21, world_size=2, collective=lambda t: t.mul_(2.0))
+    nb = len(ra.ranges)
+    assert nb >= 8
+    for step in range(3):
+        zr, zt, tg = z_refcat.cuda() * (1 + 0.1 * step), z_tag.cuda() + 0.01 * step, target.cuda()
+        la, pa = a.forward_backward(zr, zt, tg, 1, ehs.cuda(), reducer=ra)
+        la = ra.finish().clone()
+        order_a = list(ra.fired_order)
+        lb, pb = b.forward_backward_segmented(zr, zt, tg, 1, ehs.cuda(), rb)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(la, lb), step
+        assert torch.equal(a.P.grad, b.P.grad), step
+        assert list(rb.fired_order) == order_a and sorted(order_a) == list(range(nb)), step
+        a.optimizer_step(1e-4)
+        b.optimizer_step(1e-4)
+        assert torch.equal(a.P.master, b.P.master)
+    key = [k for k in b._graphs if k[0] == "segmented"]
+    assert len(key) == 1 and 2 <= len(b._graphs[key[0]][0]) <= nb + 1 and b.graph_nodes > 500
+
+
 def test_captured_training_step_equals_eager(hip_lib):
     """forward_backward_captured: fwd + bwd replayed as one HIP graph == the eager step bit for bit (loss, pred, the whole
     flat gradient), over optimizer steps in between (the derived weight copies are refreshed inside the graph) and with new

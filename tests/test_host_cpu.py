@@ -409,7 +409,7 @@ def _rank_overlapped_reduce(rank, world, port, out_dir):
     grads = torch.randn(numel, generator=g)
     loss = torch.tensor([0.25 + rank])
     res = {}
-    for mode in ("serial", "overlap_fp32", "overlap_bf16"):
+    for mode in ("serial", "overlap_fp32", "overlap_bf16", "segments_fp32"):
         buf = torch.zeros(numel + ParamStore.TAIL)
         if mode == "serial":
             buf[:numel] = grads
@@ -418,7 +418,41 @@ def _rank_overlapped_reduce(rank, world, port, out_dir):
             res[mode] = buf.clone()
             continue
         red = GradBucketReducer(buf, spec, bucket_elems=50_000,
-                                comm_dtype=torch.float32 if mode == "overlap_fp32" else torch.bfloat16)
+                                comm_dtype=torch.bfloat16 if mode == "overlap_bf16" else torch.float32)
+        if mode == "segments_fp32":
+            # replay_segments: the captured-step form -- each "graph" writes the gradients of one cut of the backward, the
+            # reducer fires that cut's buckets behind it (segments planned the way _SegmentRecorder cuts a capture)
+            from diffews_amd.train import replay_segments
+            red.reset_state()
+            names = list(spec)[::-1]
+            segs, cur = [], []
+            for nme in names:
+                cur.append(nme)
+                ready = red.ready_after([nme])
+                if ready:
+                    for b in ready:
+                        red.fired[b] = True
+                    segs.append((list(cur), ready))
+                    cur = []
+            rest = [b for b in range(len(red.ranges) - 1, -1, -1) if not red.fired[b]]
+            segs.append((list(cur), rest))
+            red.active = False
+
+            class _G:
+                def __init__(self, ns, first):
+                    self.ns, self.first = ns, first
+
+                def replay(self):
+                    if self.first:
+                        buf[numel] = loss[0]
+                    for nme in self.ns:
+                        o, n = spec[nme]
+                        buf[o:o + n] = grads[o:o + n]
+            avg = replay_segments([(_G(ns, i == 0), bs) for i, (ns, bs) in enumerate(segs)], red)
+            res[mode] = buf.clone()
+            res[mode + "_loss"] = avg.clone()
+            res[mode + "_order"] = list(red.fired_order)
+            continue
         red.begin(loss)
         # the "backward": parameters become final from the end of the buffer towards its start, in uneven groups;
         # the same order on every rank (it is a property of the model, not of the data)
@@ -477,3 +511,8 @@ def test_two_rank_overlapped_gradient_reduce_equals_serial(tmp_path):
     assert len(r0["overlap_fp32_order"]) >= 8
     d = (r0["overlap_bf16"][:-64] - r0["serial"][:-64]).norm() / r0["serial"][:-64].norm()
     assert float(d) < 8e-3 and torch.equal(r0["overlap_bf16"], r1["overlap_bf16"])
+    # round 4: the captured-step form (a chain of segments cut at the bucket boundaries, replay_segments) is the same
+    # reduction bit for bit, on both ranks, in the same firing order
+    assert torch.equal(r0["segments_fp32"], r0["serial"]) and torch.equal(r1["segments_fp32"], r0["serial"])
+    assert r0["segments_fp32_order"] == r0["overlap_fp32_order"] == r1["segments_fp32_order"]
+    assert float(r0["segments_fp32_loss"]) == pytest.approx((0.25 + 1.25) / 2)
