@@ -201,6 +201,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
     asm volatile("" : "+v"(lane_e));
     const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
     if constexpr (F32O) {
+      GnRegSums gsum;
+      gsum.clear();
 #pragma unroll
       for (int i = 0; i < MB6; ++i) {
         const int m = row_to_m(c, wm * WTM + i * 16 + l15);
@@ -236,7 +238,13 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const GemmP p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (acc6[i][j][e] + add[j][e]) * p.out_scale;
           *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = v;
+          gsum.add(j, v);
         }
+      }
+      if (p.gn_partial) {       // statistics of the fp32 values just stored (the next GroupNorm skips its own pass)
+        const int tm = tile_id / p.ntn;
+        const int chunk = (tm - c.img * p.tpi) * WGM + wm;
+        gsum.store(p, p.gn_partial + ((size_t)c.img * p.gn_chunks + chunk) * p.gn_groups * 2, c.n0 + wn * 64, lane);
       }
       return;
     }
@@ -448,7 +456,7 @@ bool conv_patch_eligible(const GemmP& p, int& bm, int& bn) {
 
 int conv_patch_gn_chunks(const GemmP& p) {
   int bm = 0, bn = 0;
-  if (p.gn_groups <= 0 || p.out_mode != DFW_OUT_T || !conv_patch_eligible(p, bm, bn) || p.N % p.gn_groups) return 0;
+  if (p.gn_groups <= 0 || (p.out_mode != DFW_OUT_T && p.out_mode != DFW_OUT_F32) || !conv_patch_eligible(p, bm, bn) || p.N % p.gn_groups) return 0;
   const int cpg = p.N / p.gn_groups;
   if (cpg < 4 || cpg > 64 || (cpg & (cpg - 1))) return 0;
   return (p.Wo / 16) * (p.Ho / (bm / 16)) * (8 / (bn / 64));
@@ -460,8 +468,8 @@ int launch_conv_patch(const GemmP& p, hipStream_t st) {
   const int chunks = conv_patch_gn_chunks(p);
   const bool bf = p.dtype_bf16 != 0;
   if (p.out_mode == DFW_OUT_F32) {
-    if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, true>(p, st, 0) : launch_patch<_Float16, 512, 128, true>(p, st, 0);
-    return bf ? launch_patch<__bf16, 256, 256, true>(p, st, 0) : launch_patch<_Float16, 256, 256, true>(p, st, 0);
+    if (bm == 512) return bf ? launch_patch<__bf16, 512, 128, true>(p, st, chunks) : launch_patch<_Float16, 512, 128, true>(p, st, chunks);
+    return bf ? launch_patch<__bf16, 256, 256, true>(p, st, chunks) : launch_patch<_Float16, 256, 256, true>(p, st, chunks);
   }
   if (bm == 512) return bf ? launch_patch<__bf16, 512, 128>(p, st, chunks) : launch_patch<_Float16, 512, 128>(p, st, chunks);
   return bf ? launch_patch<__bf16, 256, 256>(p, st, chunks) : launch_patch<_Float16, 256, 256>(p, st, chunks);

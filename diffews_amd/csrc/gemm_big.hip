@@ -404,6 +404,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
       asm volatile("" : "+v"(lane_e));
       const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
       if constexpr (F32O) {
+        GnRegSums gsum;
+        gsum.clear();
 #pragma unroll
         for (int i = 0; i < MB6; ++i) {
           int oy_ = 0, ox_ = 0, img_ = 0;
@@ -442,7 +444,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_big_kernel(const GemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (acc6[i][j][e] + add[j][e]) * p.out_scale;
             *(f32x4*)(Cb + ((size_t)m * p.ldc + n) * sizeof(float)) = v;
+            gsum.add(j, v);
           }
+        }
+        if (p.gn_partial) {     // conv tiles are whole (every row stored): statistics of the fp32 values just written
+          const int tm = tile_id / p.ntn;
+          const int chunk = (tm - c.img * p.tpi) * WGM + wm;
+          gsum.store(p, p.gn_partial + ((size_t)c.img * p.gn_chunks + chunk) * p.gn_groups * 2, c.n0 + wn * 64, lane);
         }
         return;
       }
@@ -743,7 +751,8 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk) {
 
 int gemm_big_gn_chunks(const GemmP& p) {
   int bm = 0, bn = 0, bk = 0;
-  if (p.gn_groups <= 0 || p.taps != 9 || p.geglu || p.out_mode != DFW_OUT_T || !gemm_big_eligible(p, bm, bn, bk)) return 0;
+  if (p.gn_groups <= 0 || p.taps != 9 || p.geglu || (p.out_mode != DFW_OUT_T && p.out_mode != DFW_OUT_F32) ||
+      !gemm_big_eligible(p, bm, bn, bk)) return 0;
   if ((size_t)(bm + bn) * bk * 2 < 8 * 4096) return 0;            // staged epilogue needs a 32 KiB slot
   if (p.N % p.gn_groups) return 0;
   const int cpg = p.N / p.gn_groups;

@@ -188,6 +188,51 @@ __device__ __forceinline__ void epi_block_rf32(const GemmP& p, char* Cb, int m, 
     }
 }
 
+// GroupNorm partial sums of a wave's (rows x 64 channels) output block taken from REGISTERS: the 16x16x32 accumulator layout
+// gives lane (l15 = lane & 15, l4 = lane >> 4) row l15 and channels 16 j + 4 l4 .. + 3 of every 16-row block.  Used by the
+// fp32-output epilogues (the stored values ARE the fp32 values, so these are the statistics of the stored tensor).
+// add(): once per 16-row block and channel block j with the 4 stored values; store(): after the last block -- sums over
+// the 16 rows (lanes xor 1, 2, 4, 8), then over the quads of a channel group (cpg = 4 .. 64, a power of two), fixed order.
+struct GnRegSums {
+  float s[4], q[4];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  }
+  __device__ __forceinline__ void add(int j, const f32x4& v) {
+    s[j] += (v[0] + v[1]) + (v[2] + v[3]);
+    q[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  // out: p.gn_partial + ((img * gn_chunks + chunk) * gn_groups) * 2; n_w0: first channel of the wave's 64
+  __device__ __forceinline__ void store(const GemmP& p, float* out, int n_w0, int lane) {
+    const int cpg = p.N / p.gn_groups;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s[j] += __shfl_xor(s[j], o, 64);
+        q[j] += __shfl_xor(q[j], o, 64);
+      }
+      if (cpg >= 8) { s[j] += __shfl_xor(s[j], 16, 64); q[j] += __shfl_xor(q[j], 16, 64); }
+      if (cpg >= 16) { s[j] += __shfl_xor(s[j], 32, 64); q[j] += __shfl_xor(q[j], 32, 64); }
+    }
+    if (cpg >= 32) { s[0] += s[1]; q[0] += q[1]; s[2] += s[3]; q[2] += q[3]; }
+    if (cpg >= 64) { s[0] += s[2]; q[0] += q[2]; }
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if (l15 != 0) return;
+    const int lstep = cpg >= 16 ? 4 : cpg / 4;          // quads (l4 values) per group inside a 16-channel block
+    if (l4 % lstep) return;
+    const int jstep = cpg >= 64 ? 4 : (cpg >= 32 ? 2 : 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j % jstep) continue;
+      const int grp = (n_w0 + j * 16 + 4 * l4) / cpg;
+      out[grp * 2] = s[j];
+      out[grp * 2 + 1] = q[j];
+    }
+  }
+};
+
 // Tile coordinates of one output tile (uniform per workgroup).
 struct TileC {
   int m0, n0;                 // first output row (linear tiles) / first output channel

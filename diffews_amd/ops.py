@@ -273,14 +273,19 @@ def linear_stream(x, w, bias=None, residual=None):
     return linear(lo, w, residual=y, out_f32=True)
 
 
-def conv3x3_stream(x, w, cout, bias=None, **kw):
-    """conv3x3 whose INPUT is the residual stream (Downsample2D / Upsample2D convs): as linear_stream."""
+def conv3x3_stream(x, w, cout, bias=None, lo=True, **kw):
+    """conv3x3 whose INPUT is the residual stream (Downsample2D / Upsample2D convs): as linear_stream.
+    lo=False: the fp32 stream is fed as ONE operand rounded once (no second GEMM, a convert instead of the split): each such
+    conv adds one storage rounding of its input (2.5e-4 relative in fp16, in quadrature) -- the VAE encoder's two LARGEST
+    downsample convs take this form (round 4): they were 2.2 ms of the parity mode for 0.8e-4 of its 7.5e-4."""
     if x.dtype != torch.float32:
         return conv3x3(x, w, cout, bias=bias, **kw)
+    if not lo:
+        return conv3x3(to_storage(x, w.dtype), w, cout, bias=bias, out_f32=True, **kw)
     hi, lo = split_storage(x, w.dtype)
-    kw.pop("gn_groups", None)
+    gn_groups = kw.pop("gn_groups", 0)
     y = conv3x3(hi, w, cout, bias=bias, out_f32=True, **kw)
-    return conv3x3(lo, w, cout, residual=y, out_f32=True, **kw)
+    return conv3x3(lo, w, cout, residual=y, out_f32=True, gn_groups=gn_groups, **kw)     # the FINAL values carry the statistics
 
 
 FSA_QSCALE = 64 ** -0.5 * math.log2(math.e)   # attn.scale (A:269-271, head_dim 64) in exp2 units

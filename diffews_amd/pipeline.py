@@ -171,7 +171,8 @@ class MarigoldPipelineRGBLatentNoise:
             raise ValueError("residual_dtype must be None (= storage dtype) or torch.float32")
         self.unet.residual_dtype, self.unet._f32s = rd, rd == torch.float32
         self.vae.residual_dtype = vd
-        self.vae.encoder.f32s = self.vae.decoder.f32s = vd == torch.float32
+        self.vae.encoder.f32s = vd == torch.float32
+        self.vae.decoder.f32s = vd == torch.float32 and self.vae.decoder_f32_stream    # downstream of z0: 16-bit stream by default
         self._graphs = {}
         return self
 

@@ -83,6 +83,7 @@ class _Encoder:
     def __init__(self, vae, sd):
         cfg, dev, dt, g = vae.config, vae.device, vae.dtype, vae.config["norm_num_groups"]
         self.dt, self.groups, self.f32s = dt, g, vae.residual_dtype == torch.float32
+        self.single_round_levels = 2      # downsamplers of the first N levels read the fp32 stream as ONE rounded operand
         boc, lpb = list(cfg["block_out_channels"]), cfg["layers_per_block"]
         self.c0 = boc[0]
         self.w_in = packing.pack_conv_small(sd["encoder.conv_in.weight"]).to(dev)
@@ -106,11 +107,14 @@ class _Encoder:
         else:
             x = x.to(dtype=torch.float32).contiguous()
         h = ops.conv_small(x, self.w_in, self.b_in, self.c0, 9, self.dt, gn_groups=self.groups, out_f32=self.f32s)
-        for res, down in self.blocks:
+        for lvl, (res, down) in enumerate(self.blocks):
             for r in res:
                 h = r(h)
             if down is not None:  # F.pad(0,1,0,1) + conv stride 2 padding 0
-                h = ops.conv3x3_stream(h, down.w, down.cout, bias=down.b, stride=2, pad=0, gn_groups=self.groups)
+                # fp32 stream: the two high-resolution downsamplers read it rounded once (ops.conv3x3_stream lo=False), the rest
+                # as (hi, lo) pairs: see DESIGN.md section 4 for the error / time table that put the line there
+                h = ops.conv3x3_stream(h, down.w, down.cout, bias=down.b, stride=2, pad=0, gn_groups=self.groups,
+                                       lo=lvl >= self.single_round_levels)
         h = self.mid(h)
         h = ops.groupnorm(h, *self.gn_out, self.groups, 1e-6, silu=True, out_dtype=self.dt)
         co = self.conv_out
@@ -120,7 +124,7 @@ class _Encoder:
 class _Decoder:
     def __init__(self, vae, sd):
         cfg, dev, dt, g = vae.config, vae.device, vae.dtype, vae.config["norm_num_groups"]
-        self.dt, self.groups, self.f32s = dt, g, vae.residual_dtype == torch.float32
+        self.dt, self.groups, self.f32s = dt, g, (vae.residual_dtype == torch.float32 and vae.decoder_f32_stream)
         boc, lpb = list(cfg["block_out_channels"]), cfg["layers_per_block"]
         rboc = boc[::-1]
         self.c0 = rboc[0]
@@ -195,10 +199,13 @@ class _EncOut:
 
 class AutoencoderKL:
     """residual_dtype: None (= torch_dtype) or torch.float32 -- storage of the residual stream, see
-    MyUNet2DConditionModel.  The encoder carries 1.3 of the 1.45e-3 fp16 error of the 16-bit stream."""
+    MyUNet2DConditionModel.  The encoder carries 1.3 of the 1.45e-3 fp16 error of the 16-bit stream.
+    decoder_f32_stream (round 4, default False): the fp32 stream applies to the ENCODER only.  The decoder is downstream of
+    the parity tensor (the predicted latent z0, P:769) and its output is quantised to uint8 (P:534), where the 16-bit
+    stream's error is 0.15 levels; running it with the fp32 stream bought nothing measurable and cost ~4 ms per step."""
 
     def __init__(self, config=None, state_dict=None, torch_dtype=torch.bfloat16, device="cuda", residual_dtype=None,
-                 **kwargs):
+                 decoder_f32_stream=False, **kwargs):
         cfg = weights.default_vae_config()
         cfg.update(config or {})
         cfg.update(kwargs)
@@ -206,6 +213,7 @@ class AutoencoderKL:
         if residual_dtype not in (None, torch_dtype, torch.float32):
             raise ValueError("residual_dtype must be None (= torch_dtype) or torch.float32")
         self.residual_dtype = residual_dtype or torch_dtype
+        self.decoder_f32_stream = bool(decoder_f32_stream)
         if torch_dtype not in (torch.bfloat16, torch.float16):
             raise ValueError(
                 "engine storage dtype must be torch.bfloat16 or torch.float16: the MI355X path keeps activations in 16 bits "
@@ -241,7 +249,8 @@ class AutoencoderKL:
         if _needs_rebuild(self, device, dtype):
             self.__init__(dict(self.config), self._sd_cpu, torch_dtype=dtype or self.dtype,
                           device=device or self.device,
-                          residual_dtype=torch.float32 if self.residual_dtype == torch.float32 else None)
+                          residual_dtype=torch.float32 if self.residual_dtype == torch.float32 else None,
+                          decoder_f32_stream=self.decoder_f32_stream)
         return self
 
     def eval(self):

@@ -30,7 +30,7 @@ for dt in dts:
         del ref
     del ou, ov
     torch.cuda.empty_cache()
-    for modes in ((None, None), (torch.float32, None), (None, torch.float32), (torch.float32, torch.float32)):
+    for modes in (((None, None), (torch.float32, torch.float32)) if os.environ.get("F32_ONLY") else ((None, None), (torch.float32, None), (None, torch.float32), (torch.float32, torch.float32))):
         rv, ru = modes
         pipe = MarigoldPipelineRGBLatentNoise(MyUNet2DConditionModel(ucfg, usd, torch_dtype=dt, residual_dtype=ru),
                                               AutoencoderKL(vcfg, vsd, torch_dtype=dt, residual_dtype=rv),

@@ -176,6 +176,19 @@ def test_conv_fused_groupnorm_stats(ops, dtype, B, H, W, Cin, Cout):
     ref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, g, b, eps=1e-6)).permute(0, 2, 3, 1)
     assert rel(fused, ref) < TOL[dtype] and rel(plain, ref) < TOL[dtype]
     assert rel(fused, plain) < 1e-3
+    # fp32 residual stream (round 4): the fp32-output epilogues emit the sums of the fp32 values they store, from registers
+    res = torch.randn(B, H, W, Cout).cuda()
+    y32 = ops.conv3x3(x, w, Cout, bias=bias, residual=res, out_f32=True, gn_groups=32)
+    assert y32.dtype == torch.float32
+    if Cout == 128:       # 96 tiles of 512 x 128: below the big kernels' tile threshold in the fp32-output plan -> no fused sums
+        return
+    assert getattr(y32, "_gn_stats", None) is not None, "fused statistics expected (fp32 output)"
+    fused = ops.groupnorm(y32, g, b, 32, 1e-6, silu=True, out_dtype=dtype)
+    plain = ops.groupnorm(y32.clone(), g, b, 32, 1e-6, silu=True, out_dtype=dtype)
+    ref = F.silu(F.group_norm(y32.permute(0, 3, 1, 2), 32, g, b, eps=1e-6)).permute(0, 2, 3, 1)
+    assert rel(fused, ref) < TOL[dtype] and rel(fused, plain) < 1e-3
+    st2 = ops.conv3x3(x, w, Cout, bias=bias, residual=res, out_f32=True, gn_groups=32)._gn_stats[0]
+    assert torch.equal(st2, y32._gn_stats[0])          # fixed summation order
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
