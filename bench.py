@@ -568,6 +568,8 @@ def main():
                     help="skip the fp32-stream / configs[2] / configs[4] measurements that follow the headline one (N=1 only)")
     ap.add_argument("--cfg", action="append", default=[], metavar="FIELD=INT",
                     help="dfw_config field for this run (A/B of kernel plans, e.g. --cfg k8=0); not a default-changing flag")
+    ap.add_argument("--vae-flash", default="auto", choices=["auto", "on", "off"],
+                    help="VAE mid-block attention: flash kernel (no N x N scores), materialised scores, or per shape (default)")
     ap.add_argument("--inline", action="store_true",
                     help="run the headline and the secondary measurements in THIS process (default: two child processes, so "
                          "that a failure in a secondary leg cannot take the headline value with it); needed under rocprofv3")
@@ -634,6 +636,8 @@ def main():
     pipe, blobs = build_pipeline(dtype, tiny=args.tiny)
     if args.residual_dtype == "fp32":
         pipe.set_residual_dtype(torch.float32)
+    if args.vae_flash != "auto":
+        pipe.vae.encoder.mid.att.flash = pipe.vae.decoder.mid.att.flash = args.vae_flash == "on"
 
     b, s, res = args.batch, (1 if args.nshot is None else args.nshot), args.res
     bt = episodes.make_episode_batch(b, s, res, seed=100 + rank, device="cuda")

@@ -120,6 +120,13 @@ class AttnBwdArgs(C.Structure):
                 ("scale", _f32), ("dtype", _i32), ("workspace", _vp), ("workspace_bytes", _sz), ("delta_bytes", _sz)]
 
 
+class VattnArgs(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("out", _vp),
+                ("batch", _i32), ("n", _i32), ("head_dim", _i32), ("q_prescaled", _i32),
+                ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32),
+                ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("o_bs", _i64), ("dtype", _i32)]
+
+
 class AdamWArgs(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("grad_sumsq", _vp), ("n", _i64),
                 ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_grad_norm", _f32),
@@ -146,6 +153,7 @@ SYMBOLS = {
     "dfw_fsa_attention": (_i32, [C.POINTER(FsaArgs), _vp]),
     "dfw_fsa_workspace_bytes": (_sz, [C.POINTER(FsaArgs)]),
     "dfw_cross_attention": (_i32, [C.POINTER(XattnArgs), _vp]),
+    "dfw_vae_attention": (_i32, [C.POINTER(VattnArgs), _vp]),
     "dfw_groupnorm": (_i32, [C.POINTER(GroupNormArgs), _vp]),
     "dfw_groupnorm_workspace_bytes": (_sz, [C.POINTER(GroupNormArgs)]),
     "dfw_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),

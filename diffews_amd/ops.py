@@ -291,6 +291,26 @@ def conv3x3_stream(x, w, cout, bias=None, lo=True, **kw):
 FSA_QSCALE = 64 ** -0.5 * math.log2(math.e)   # attn.scale (A:269-271, head_dim 64) in exp2 units
 
 
+VATTN_QSCALE = 512 ** -0.5 * math.log2(math.e)   # the VAE mid-block attention's scale (one head of dim 512) in exp2 units
+
+
+def vae_attention(q, k, v, out=None):
+    """Flash attention of the VAE mid-block: q / k / v [B, N, 512] views (column slices of one fused QKV buffer), ONE head of
+    dim 512, q pre-multiplied by VATTN_QSCALE (linear(..., colscale=(512, VATTN_QSCALE))).  The N x N scores stay on chip."""
+    B, N, D = q.shape
+    assert D == 512 and k.shape == q.shape and v.shape == q.shape and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        out = torch.empty(B, N, D, dtype=q.dtype, device=q.device)
+    a = L.VattnArgs()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.batch, a.n, a.head_dim, a.q_prescaled = B, N, D, 1
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.dtype = _dt(q)
+    L.check(L.lib().dfw_vae_attention(C.byref(a), _stream()), "dfw_vae_attention")
+    return out
+
+
 def cross_attention(q, k, v, heads, scale=None):
     """q [B, N, heads*64]; k/v [B, L, heads*64] views (short context)."""
     B, N, Cq = q.shape

@@ -154,6 +154,12 @@ class MarigoldPipelineRGBLatentNoise:
         return self
 
     def enable_xformers_memory_efficient_attention(self, *a, **k):
+        """E:374-376.  The UNet's KV-fusion attention is always the memory-efficient (flash) kernel; for the VAE's mid-block
+        attention this call selects the flash kernel too (csrc/vae_attention.hip: no N x N score tensor), as xformers does in
+        the reference.  Without the call the VAE picks per shape (vae._VaeAttention.flash = "auto")."""
+        for half in (self.vae.encoder, self.vae.decoder):
+            half.mid.att.flash = True
+        self._graphs = {}
         return None
 
     @property

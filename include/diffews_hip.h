@@ -530,6 +530,21 @@ size_t dfw_cross_attention_bwd_workspace_bytes(int32_t batch, int32_t heads, int
 /* y = silu(a) (dy == NULL) or y = dy * silu'(a), n storage-dtype elements (the timestep-embedding MLP). */
 int dfw_silu(const void* a, const void* dy, void* y, int64_t n, int32_t dtype, dfw_stream_t stream);
 
+/* Memory-efficient attention of the VAE mid-block (diffusers AutoencoderKL `Attention`: ONE head of dim 512 over N = h * w
+ * tokens; the reference routes it through xformers memory_efficient_attention, evaluation_util/main_oss.py:374-376, so the
+ * N x N scores are never materialised): out[b][i] = softmax_j(q[b][i] . k[b][j]) v[b][j], flash-style, fp32 statistics.
+ * q / k / v / out: [batch][n][ld* >= 512] views (16-byte aligned, ld % 8 == 0; column slices of one fused QKV buffer are
+ * fine), batch strides in elements.  q must arrive multiplied by head_dim^-0.5 * log2(e) (dfw_gemm_args.colscale of the
+ * projection that produced it): q_prescaled != 0 is required, head_dim must be 512.  Any n (keys beyond n are masked). */
+typedef struct {
+  const void* q; const void* k; const void* v; void* out;
+  int32_t batch, n, head_dim, q_prescaled;
+  int32_t ldq, ldk, ldv, ldo;
+  int64_t q_bs, k_bs, v_bs, o_bs;
+  int32_t dtype;
+} dfw_vattn_args;
+int dfw_vae_attention(const dfw_vattn_args* a, dfw_stream_t stream);
+
 /* Sum of squares of an fp32 vector (the global gradient norm of clip_grad_norm_, T:1393); workspace: 1024 floats. */
 int dfw_sumsq(const float* x, float* out, float* workspace, int64_t n, dfw_stream_t stream);
 

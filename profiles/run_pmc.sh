@@ -5,14 +5,14 @@
 # domains); FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, rocprofv3 PMC slots); the SQ /
 # GRBM counters for MFMA utilisation share a third pass.  The program itself follows `--` (no env/bash hop).
 set -e -o pipefail
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 shift || true
 EXTRA="$@"
 REPO=$(pwd)
 python3 -m diffews_amd.build > /dev/null      # never rebuild under the profiler (DFW_NO_BUILD below)
 export DFW_NO_BUILD=1
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph --no-secondary $EXTRA"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph --no-secondary --inline $EXTRA"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${ROUND}_$C
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${ROUND}_$C -o runc -- python3 $ARGS > gpurun_out/pmc_${ROUND}_$C.log 2>&1

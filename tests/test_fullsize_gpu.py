@@ -244,6 +244,45 @@ def test_fullsize_episode_against_oracle_on_device(hip_lib, dt, rdt):
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_vae_flash_attention_equals_materialised(hip_lib, dt):
+    """SD VAE (512-channel mid-block) with the flash mid-block attention (csrc/vae_attention.hip, what
+    enable_xformers_memory_efficient_attention() selects, E:374-376) against the materialised-scores path of rounds 1-3: encoder
+    moments and decoder output agree to the rounding of the 16-bit probabilities (256^2 -> 32 x 32 tokens; 192 x 320 -> 960 tokens:
+    a partial query block).  A token count off the 64 grid (200 x 328 -> 25 x 41 = 1025: masked key tail), which the
+    materialised path cannot run at all, is picked up by "auto" and checked against the fp32 oracle on the device."""
+    from diffews_amd import config
+    from diffews_amd.vae import AutoencoderKL
+    from oracle.vae import OracleVAE
+    vcfg = config.get("sd_vae")
+    vae = AutoencoderKL(vcfg, _sd("vae", dt), torch_dtype=dt)
+    assert vae.encoder.mid.att.flash == "auto"
+    g = torch.Generator().manual_seed(3)
+    tol = 3e-3 if dt == torch.float16 else 2e-2
+    for H, W in ((256, 256), (192, 320)):
+        x = (torch.rand(2, 3, H, W, generator=g) * 2 - 1).cuda()
+        z = (torch.randn(2, 4, H // 8, W // 8, generator=g)).cuda()
+        outs = {}
+        for flash in (False, True):
+            vae.encoder.mid.att.flash = vae.decoder.mid.att.flash = flash
+            outs[flash] = (vae.encoder(x), vae.decoder(vae.post_quant_conv(z)))
+        assert rel(outs[True][0], outs[False][0]) < tol and rel(outs[True][1], outs[False][1]) < tol, (H, W)
+    vae.encoder.mid.att.flash = vae.decoder.mid.att.flash = "auto"
+    ov = OracleVAE(**{k: v for k, v in vcfg.items() if not k.startswith("_")})
+    ov.load_state_dict(_sd("vae", dt)); ov.eval().cuda()
+    prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        x = (torch.rand(1, 3, 200, 328, generator=g) * 2 - 1).cuda()
+        with torch.no_grad():
+            ref_m = ov.quant_conv(ov.encoder(x))
+            ref_d = ov.decode(ref_m[:, :4])
+        assert rel(vae.quant_conv(vae.encoder(x)), ref_m) < 1.5 * tol
+        assert rel(vae.decoder(vae.post_quant_conv(ref_m[:, :4].contiguous())), ref_d) < 1.5 * tol
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
+
+
 def test_fullsize_other_resolutions_against_oracle_on_device(hip_lib):
     """Resolutions whose latent sizes do not fit the 16x16-pixel conv tiles or the 256-row attention blocks
     (384x384 -> 48x48 ... 6x6, 320x512 2-shot; scratch/other_res.py also covers 448, 768, 64): the ragged
@@ -364,6 +403,8 @@ def _fullsize_train_case(dt, nshot, res, sample_vae, seed):
     assert set(gd) == set(gref), set(gd) ^ set(gref)
     out["pred"] = rel(pred, pred_o)
     out["loss"] = abs(float(loss) - loss_o) / abs(loss_o)
+    own = float(torch.nn.functional.mse_loss(pred.float(), target.float()))        # the loss kernel alone: fp32 sum of its own fp32 pred
+    out["loss_own"] = abs(float(loss) - own) / abs(own)
     per = sorted(((rel(gd[k], gref[k]), k, float(gref[k].norm())) for k in gref), reverse=True)
     out["worst"] = per[:5]
     keys = sorted(gref)
@@ -403,6 +444,7 @@ def test_fullsize_training_step_against_oracle_autograd(hip_lib, dt, nshot, samp
     assert r["flat_rel"] <= 1.25 * r["autocast_flat_rel"], (r["flat_rel"], r["autocast_flat_rel"])
     assert r["pred"] <= 1.25 * r["autocast_pred"], (r["pred"], r["autocast_pred"])
     assert r["pred"] < (TRAIN_TOL["pred_bf16"] if bf else TRAIN_TOL["pred_fp16"]), r["pred"]
+    assert r["loss_own"] < 1e-5, r["loss_own"]
     assert r["loss"] < (TRAIN_TOL["loss_bf16"] if bf else TRAIN_TOL["loss_fp16"]), r["loss"]
     assert r["flat_rel"] < (TRAIN_TOL["flat_bf16"] if bf else TRAIN_TOL["flat_fp16"]), r["flat_rel"]
     assert r["cos"] > (TRAIN_TOL["cos_bf16"] if bf else TRAIN_TOL["cos_fp16"]), r["cos"]
@@ -415,8 +457,13 @@ def test_fullsize_training_step_against_oracle_autograd(hip_lib, dt, nshot, samp
 #   bf16 7-shot: pred 1.242e-2, loss 2.8e-4, flat gradient rel L2 3.79e-3, cos 0.999993, worst tensor 1.37e-2 (mid-block attn1.to_k)
 #   fp16 7-shot: pred 1.543e-3, loss 1.2e-5, flat 4.28e-4, cos 1.000000, worst tensor 5.2e-3 (up_blocks.3 attn1.to_q)
 #   bf16 2-shot, sampled VAE: latents 6.13e-3, pred 1.674e-2, loss 1.8e-4, flat 5.34e-3, cos 0.999986, worst tensor 2.09e-2
-# (the loss errors sit at fp32 summation noise: their bound is 2 x measured.)  The worst tensors are always attn1.to_q / to_k
+# The loss kernel itself is checked exactly (fp32 MSE of the engine's own fp32 pred: loss_own < 1e-5).  The loss against the
+# ORACLE's loss is the projection of the pred error d on r = pred - target, 2<d, r>/|r|^2 <= 2 |d|/|r|: a scalar that moves
+# with the draw -- profiles/r04_train_loss_k8.log has 1.8e-4, 8.9e-4 (round-3 kernels, seeds 62 / 63) and 1.1e-3, 6.6e-4
+# (round-4 kernels) for the same case, at unchanged pred / gradient errors.  Its bound is 8 % of the Cauchy-Schwarz limit
+# 2 x pred tolerance (a 16-bit error field that lined up with r beyond that would be a bias, not rounding).
+# The worst tensors are always attn1.to_q / to_k
 # of the small-gradient layers (|g| ~ 7e-3 of a flat norm ~ 1): dS = P o (dP - delta) cancels there, so the 16-bit
 # rounding of P and dS weighs most.
-TRAIN_TOL = dict(pred_bf16=2.1e-2, pred_fp16=1.95e-3, loss_bf16=6e-4, loss_fp16=3e-5, flat_bf16=6.7e-3, flat_fp16=5.4e-4,
+TRAIN_TOL = dict(pred_bf16=2.1e-2, pred_fp16=1.95e-3, loss_bf16=3.4e-3, loss_fp16=3.1e-4, flat_bf16=6.7e-3, flat_fp16=5.4e-4,
                  cos_bf16=0.99998, cos_fp16=0.999999, tensor_bf16=2.6e-2, tensor_fp16=6.5e-3, latents_bf16=7.7e-3)

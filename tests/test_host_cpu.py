@@ -48,7 +48,7 @@ def test_struct_layouts_match_header():
                        ("dfw_groupnorm_bwd_args", _lib.GroupNormBwdArgs), ("dfw_layernorm_bwd_args", _lib.LayerNormBwdArgs),
                        ("dfw_fsa_bwd_args", _lib.FsaBwdArgs), ("dfw_xattn_bwd_args", _lib.XattnBwdArgs),
                        ("dfw_attn_bwd_args", _lib.AttnBwdArgs), ("dfw_adamw_args", _lib.AdamWArgs), ("dfw_image_args", _lib.ImageArgs),
-                       ("dfw_config", _lib.Config)):
+                       ("dfw_vattn_args", _lib.VattnArgs), ("dfw_config", _lib.Config)):
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", hdr).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -66,7 +66,8 @@ def test_sizeof_structs_against_compiler(tmp_path):
     src = tmp_path / "sz.c"
     names = ["dfw_gemm_args", "dfw_fsa_args", "dfw_xattn_args", "dfw_groupnorm_args", "dfw_layernorm_args",
              "dfw_conv_small_args", "dfw_gemm_tn_args", "dfw_groupnorm_bwd_args", "dfw_layernorm_bwd_args",
-             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_attn_bwd_args", "dfw_adamw_args", "dfw_image_args", "dfw_config"]
+             "dfw_fsa_bwd_args", "dfw_xattn_bwd_args", "dfw_attn_bwd_args", "dfw_adamw_args", "dfw_image_args", "dfw_vattn_args",
+             "dfw_config"]
     src.write_text('#include <stdio.h>\n#include "diffews_hip.h"\nint main(){' +
                    "".join(f'printf("%zu ", sizeof({n}));' for n in names) + 'return 0;}\n')
     exe = tmp_path / "sz"
@@ -75,7 +76,8 @@ def test_sizeof_structs_against_compiler(tmp_path):
     assert sizes == [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.FsaArgs, _lib.XattnArgs, _lib.GroupNormArgs,
                                                 _lib.LayerNormArgs, _lib.ConvSmallArgs, _lib.GemmTnArgs,
                                                 _lib.GroupNormBwdArgs, _lib.LayerNormBwdArgs, _lib.FsaBwdArgs,
-                                                _lib.XattnBwdArgs, _lib.AttnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs, _lib.Config)]
+                                                _lib.XattnBwdArgs, _lib.AttnBwdArgs, _lib.AdamWArgs, _lib.ImageArgs, _lib.VattnArgs,
+                                                _lib.Config)]
 
 
 def test_library_reads_nothing_from_the_environment():
@@ -370,7 +372,8 @@ def test_kernel_plans_of_the_baseline_shapes():
     assert not name(8 * 64 * 64, 320, 9 * 320, 9, 64, 64).startswith("conv_patch_kernel")
     # UNet, lock-step batch of 8 latents: narrow tiles for the short-K linears, the ragged 960-column QKV on gemm_big
     assert name(8192, 640, 640) in ("gemm_kernel<bf16,64,64,lin>", "gemm_kernel<bf16,128,64,lin>")   # never 128 x 128 (+47 %)
-    assert name(32768, 960, 320).startswith("gemm_big_kernel<bf16,512,128")
+    assert name(32768, 960, 320) == "gemm8_kernel<bf16,256,128,64,lin>"          # round 4: the 64-deep K-tile kernel, 256 x 128 tile
+    assert name(32768, 2560, 320) == "gemm8_kernel<bf16,256,256,64,lin>"
     assert name(32768, 320, 320).startswith("gemm_kernel<bf16,")
 
     def fsa_ws(batch, n_plain, nshot, heads, n):

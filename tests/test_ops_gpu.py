@@ -531,6 +531,53 @@ def test_fsa_attention_key_split(ops, dtype, b, nshot, heads, N, n_plain_mode):
     assert rel(split[-b:], ref_q) < 1.5 * TOL[dtype]
 
 
+def _vattn_ref(q, k, v):
+    s = torch.bmm(q.double(), k.double().transpose(1, 2)) * 512 ** -0.5
+    return torch.bmm(torch.softmax(s, -1), v.double()).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N", [(2, 4096), (1, 1024), (3, 1680), (1, 100), (2, 33)])
+def test_vae_attention(ops, dtype, B, N):
+    """Flash attention of the VAE mid-block (one head of dim 512, csrc/vae_attention.hip) against an fp64 softmax attention
+    over the materialised scores: whole and ragged key tiles (N % 32 != 0: masked keys, unstored query rows), column-slice
+    views of one fused QKV buffer, q pre-scaled as the fused projection leaves it."""
+    qkv = rnd((B, N, 1536), dtype, 1).cuda()
+    q, k, v = qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:]
+    qs = (q.float() * ops.VATTN_QSCALE).to(dtype)               # what linear(..., colscale=(512, VATTN_QSCALE)) hands over
+    buf = torch.cat([qs, k, v], -1).contiguous()
+    y = ops.vae_attention(buf[..., :512], buf[..., 512:1024], buf[..., 1024:])
+    ref = _vattn_ref(qs.float() / ops.VATTN_QSCALE, k.float(), v.float())
+    assert y.shape == (B, N, 512) and rel(y, ref) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert torch.equal(y, ops.vae_attention(buf[..., :512], buf[..., 512:1024], buf[..., 1024:]))     # deterministic
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("spike_at", [40, 700, 1023, 2047])
+def test_vae_attention_reference_restart(ops, dtype, spike_at):
+    """The flash kernel takes the first key tile's row maximum as its reference and never rescales its accumulators inside
+    the tile loop: a later score more than 2^8 above the reference makes the WORKGROUP leave the loop, compute the exact row
+    maxima in one extra pass and start over.  Forced here: one key far along the sequence (also in the LAST tile) matches a
+    block of queries ~30 log2 units better than anything before it, in one workgroup only (the other workgroups of the launch
+    take the plain path); checked against the fp64 reference on the whole tensor."""
+    B, N = 1, 2048
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B, N, 512, generator=g) * 0.3
+    k = torch.randn(B, N, 512, generator=g) * 0.3
+    v = torch.randn(B, N, 512, generator=g)
+    u = torch.randn(512, generator=g)
+    u = u / u.norm()
+    q[0, 300:420] += 25.0 * u          # rows 300..419 (workgroups 2 and 3) ...
+    k[0, spike_at] += 25.0 * u          # ... meet this key: + 625 / sqrt(512) * log2(e) ~ 40 log2 units
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    qs = (q.float() * ops.VATTN_QSCALE).to(dtype).cuda()
+    y = ops.vae_attention(qs, k.cuda(), v.cuda())
+    ref = _vattn_ref(qs.float().cpu() / ops.VATTN_QSCALE, k.float(), v.float())
+    assert torch.isfinite(y).all()
+    assert rel(y, ref) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert rel(y[0, 300:420], ref[0, 300:420]) < (8e-3 if dtype == torch.bfloat16 else 1.5e-3)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("L", [2, 77])
 def test_cross_attention(ops, dtype, L):
