@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffews_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm8.hip", "conv_patch.hip", "attention.hip", "vae_attention.hip", "attention_bwd.hip", "backward.hip", "norm.hip",
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm8.hip", "conv_patch.hip", "conv_patch8.hip", "attention.hip", "vae_attention.hip", "attention_bwd.hip", "backward.hip", "norm.hip",
            "misc.hip", "preprocess.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-unused-value"]
 

@@ -497,6 +497,10 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   int big_bm = 0, big_bn = 0, big_bk = 0;
   {
     int pbm = 0, pbn = 0;
+    if (conv_patch8_eligible(p, pbn)) {
+      snprintf(buf, n, "conv_patch8_kernel<%s,256,%d>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbn);
+      return 0;
+    }
     if (conv_patch_eligible(p, pbm, pbn)) {
       snprintf(buf, n, "conv_patch_kernel<%s,%d,%d>", a->dtype == DFW_BF16 ? "bf16" : "f16", pbm, pbn);
       return 0;
@@ -521,6 +525,7 @@ extern "C" int32_t dfw_gemm_gn_chunks(const dfw_gemm_args* a) {
   int esz;
   if (fill_params(a, p, esz)) return 0;
   int pbm = 0, pbn = 0;
+  if (conv_patch8_eligible(p, pbn)) return conv_patch8_gn_chunks(p);
   if (conv_patch_eligible(p, pbm, pbn)) return conv_patch_gn_chunks(p);
   return gemm_big_gn_chunks(p);
 }
@@ -544,6 +549,7 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
   int big_bm = 0, big_bn = 0, big_bk = 0;
   {
     int pbm = 0, pbn = 0;
+    if (conv_patch8_eligible(p, pbn)) return launch_conv_patch8(p, st);
     if (conv_patch_eligible(p, pbm, pbn)) return launch_conv_patch(p, st);
   }
   if (gemm_big_eligible(p, big_bm, big_bn, big_bk)) return launch_gemm_big(p, st);

@@ -247,5 +247,8 @@ bool gemm8_eligible(const GemmP& p, int bn);
 int launch_conv_patch(const GemmP& p, hipStream_t st);  // conv_patch.hip
 bool conv_patch_eligible(const GemmP& p, int& bm, int& bn);
 int conv_patch_gn_chunks(const GemmP& p);
+int launch_conv_patch8(const GemmP& p, hipStream_t st);  // conv_patch8.hip
+bool conv_patch8_eligible(const GemmP& p, int& bn);
+int conv_patch8_gn_chunks(const GemmP& p);
 
 }  // namespace dfw

@@ -852,13 +852,13 @@ extern "C" int dfw_graph_memset_nodes(void* graph, int32_t* n_nodes) {
   return c < 0 ? DFW_EINVAL : c;
 }
 
-static const dfw_config kDefaultCfg = {2, 1, 0, 0, 0, 0, 0, 1, 0, 192, 3};
+static const dfw_config kDefaultCfg = {3, 1, 0, 0, 0, 0, 0, 1, 0, 192, 3};
 static dfw_config g_cfg = kDefaultCfg;
 namespace dfw { const dfw_config& cfg() { return g_cfg; } }
 
 extern "C" int dfw_configure(const dfw_config* c) {
   if (!c) { g_cfg = kDefaultCfg; return 0; }
-  if (c->conv_patch < 0 || c->conv_patch > 2 || c->fsa_force_splits < 0 || c->big_min_tiles < 1 || c->k8 < 0 || c->k8 > 3) return DFW_EINVAL;
+  if (c->conv_patch < 0 || c->conv_patch > 4 || c->fsa_force_splits < 0 || c->big_min_tiles < 1 || c->k8 < 0 || c->k8 > 3) return DFW_EINVAL;
   if (c->gemm_bm && !((c->gemm_bm == 128 && (c->gemm_bn == 128 || c->gemm_bn == 64)) || (c->gemm_bm == 64 && c->gemm_bn == 64))) return DFW_EINVAL;
   g_cfg = *c;
   return 0;

@@ -47,7 +47,9 @@ const char* dfw_error_string(int code);
  * dfw_get_config() with the fields of interest changed.  dfw_configure(NULL) restores the defaults.  Call it before the
  * launches it should affect; it is not synchronised against concurrent launches from other threads. */
 typedef struct {
-  int32_t conv_patch;        /* conv_patch_kernel: 0 off, 1 the N = 128 conv3x3 layers only, 2 (default) also the N % 256 == 0 ones */
+  int32_t conv_patch;        /* conv_patch_kernel: 0 off, 1 the N = 128 conv3x3 layers only, 2 also the N % 256 == 0 ones; 3: conv_patch8_kernel
+                                (64-channel K-tiles on the eight-phase schedule) for the N % 256 == 0 layers, 4: also its 256 x 128 tile for
+                                the other N % 64 == 0 layers */
   int32_t big_kernels;       /* 1 (default) gemm_big_kernel where eligible; 0: gemm_kernel tiles only */
   int32_t big_bm, big_bn, big_bk;   /* != 0: force this gemm_big configuration where it fits (sweeps), e.g. 256, 128, 64 */
   int32_t gemm_bm, gemm_bn;  /* != 0: force this gemm_kernel tile (128x128, 128x64, 64x64) instead of the cost model */

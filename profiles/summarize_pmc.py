@@ -26,6 +26,9 @@ def readable(mangled):
     m = re.search(r"gemm8_kernelIDF16(b|_)Lb(\d)ELi(\d+)E", mangled)
     if m:      # the name dfw_gemm_kernel_name() gives bench.py
         return f"gemm8_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},256,{m.group(3)},64,{'conv' if m.group(2) == '1' else 'lin'}>"
+    m = re.search(r"conv_patch8_kernelIDF16(b|_)Li(\d+)E", mangled)
+    if m:      # the name dfw_gemm_kernel_name() gives bench.py
+        return f"conv_patch8_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},256,{m.group(2)}>"
     m = re.search(r"conv_patch_kernelIDF16(b|_)Li(\d+)ELi(\d+)E", mangled)
     if m:      # the name dfw_gemm_kernel_name() gives bench.py
         return f"conv_patch_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},{m.group(2)},{m.group(3)}>"

@@ -364,6 +364,53 @@ def test_gemm8_conv_gather(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(12, 128, 128, 256, 256), (3, 512, 512, 128, 128), (2, 256, 256, 64, 128), (3, 128, 128, 320, 256),
+                                            (1, 320, 336, 64, 320), (4, 64, 64, 320, 320), (2, 96, 160, 192, 512), (1, 256, 256, 128, 384),
+                                            (4, 64, 64, 512, 512)])
+def test_conv_patch8(ops, dtype, B, H, W, Cin, Cout):
+    """conv_patch8_kernel (round 4: the LDS-resident 18 x 18 x 64-channel patch on the eight-phase schedule; dfw_config.conv_patch = 4
+    plans its 256 x 256 tile for N % 256 == 0 and its 256 x 128 tile for the other N % 64 == 0 layers): against F.conv2d on the
+    same 16-bit inputs (first and last image: all four borders), against conv_patch_kernel / gemm_kernel (conv_patch = 2: same
+    products, another summation order), run-to-run bit-equal, fused GroupNorm sums.  One chunk per tile (Cin = 64: the staging
+    area and the next tile's patch alternate every tile), odd chunk counts (Cin = 320, 192), several tiles per workgroup,
+    ragged N (320 = 2.5 column tiles), N % 256 == 0 with too few 256 x 256 tiles (4 x 64^2 x 512: the 256 x 128 tile)."""
+    from diffews_amd import _lib
+    from diffews_amd.packing import pack_conv3x3
+    x = rnd((B, H, W, Cin), dtype, 1).cuda()
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, (9 * Cin) ** -0.5).cuda()
+    wp = pack_conv3x3(w.cpu()).cuda()
+    bias, rb = torch.randn(Cout).cuda(), torch.randn(B, Cout).cuda()
+    res = rnd((B, H, W, Cout), dtype, 3).cuda()
+    kw = dict(bias=bias, rowbias=rb, residual=res, out_scale=0.5, gn_groups=32)
+    try:
+        _lib.configure(conv_patch=4)
+        names = _kernel_name(ops, lambda: ops.conv3x3(x, wp, Cout, **kw))
+        assert names and names[0].startswith("conv_patch8_kernel"), names
+        y8 = ops.conv3x3(x, wp, Cout, **kw)
+        junk = torch.randn(2048, 2048, device="cuda")
+        junk = junk @ junk
+        y8b = ops.conv3x3(x, wp, Cout, **kw)
+        _lib.configure(conv_patch=2)
+        y0 = ops.conv3x3(x, wp, Cout, **kw)
+    finally:
+        _lib.configure()
+    for i in {0, B - 1}:
+        ref = F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rb[i][None, :, None, None]
+        ref = ((ref.permute(0, 2, 3, 1) + res[i:i + 1].float()) * 0.5).cpu()
+        assert rel(y8[i:i + 1].cpu(), ref) < TOL[dtype]
+    assert rel(y8, y0) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert torch.equal(y8, y8b)                                           # run-to-run: no race in the rings
+    if ((Cout // 32) & (Cout // 32 - 1)) == 0:                           # channel groups that tile the 64-column wave tiles
+        assert y8._gn_stats is not None and torch.equal(y8._gn_stats[0], y8b._gn_stats[0])
+        g, b = (torch.randn(Cout) * 0.2 + 1).cuda(), (torch.randn(Cout) * 0.2).cuda()
+        fused = ops.groupnorm(y8, g, b, 32, 1e-6, silu=True)
+        plain = ops.groupnorm(y8.clone(), g, b, 32, 1e-6, silu=True)
+        assert rel(fused, plain) < 1e-3
+    else:
+        assert getattr(y8, "_gn_stats", None) is None
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Cout", [3, 4, 8])
 def test_conv3x3_small_cout_nchw(ops, dtype, Cout):
     from diffews_amd.packing import pack_conv3x3
