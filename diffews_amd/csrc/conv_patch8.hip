@@ -377,6 +377,8 @@ static int launch_patch8(const GemmP& p, hipStream_t st, int gn_chunks) {
 // activation, enough tiles) on the 16-bit path: N % 256 == 0 -> 256 x 256 tiles, or 256 x 128 tiles where that is what fills the
 // chip (dfw_config.conv_patch >= 3); N % 64 == 0 otherwise -> 256 x 128 tiles, the last tile column ragged by 64
 // (dfw_config.conv_patch >= 4: measured slower than conv_patch_kernel<512,128> on the N = 128 layers, not the default).
+// The fp32-output layers of the fp32 residual stream stay on conv_patch_kernel<.,.,F32O>: an F32O instantiation of this kernel
+// (direct fp32 stores from the accumulators) was built and measured +0.85 ms on the parity-mode step (50.6 vs 49.7 ms).
 bool conv_patch8_eligible(const GemmP& p, int& bn) {
   const int mode = cfg().conv_patch;
   if (mode < 3) return false;
