@@ -32,13 +32,22 @@
 
 namespace dfw {
 
+// GroupNorm + SiLU of the INPUT inside this kernel (each arriving patch normalised once, in LDS, by the wave that fetched it; bit-equal
+// to the separate pass; scratch/conv_patch8_gnin_fused.patch.txt) was built and measured in round 4: the conv gets 3-33 % slower and
+// the inference step 1.15 ms slower than with dfw_groupnorm's own pass (profiles/r04_gnin_fusion.txt) -- not in the library.
 template <typename T, int BN>
 __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
-  constexpr int BM = 256, HT = 16384, PATCH = 49152;
-  constexpr int WH = BN / 128;                          // W half-tiles per K-tile
-  constexpr int WGN = BN / 64, WGM = 8 / WGN;           // wave grid
+  constexpr int BM = 256, PATCH = 49152;
+  constexpr bool N160 = BN == 160;                      // 256 x 160 tile (the N = 320 UNet layers): wave grid 4 x 2, wave tile 64 x 80
+  constexpr int WH = BN / 128;                          // W half-tiles per K-tile (BN = 160: one 160-row stage, see issue_w)
+  constexpr int WGN = N160 ? 2 : BN / 64, WGM = 8 / WGN;   // wave grid
+  constexpr int NBW = N160 ? 5 : 4;                     // 16-column blocks of a wave tile
   constexpr int WTM = BM / WGM, MB6 = WTM / 16, MH = MB6 / 2;   // wave tile rows, its pixel rows, pixel rows per quadrant
   constexpr int WB = 2 * PATCH;                         // W slots: WB + h * 32768 + buf * HT
+  // BN = 160: two 24 KiB W buffers (160 rows + 32 rows the third wave-instruction of waves 4-7 zero-fills) at 0x18000 and 0x20000:
+  // the read bases toggle by ^ 0x38000
+  constexpr uint32_t HT = N160 ? 0x38000u : 16384u;     // XOR that toggles a W read base between the two buffers
+  constexpr int WDMA = N160 ? 3 : 2 * WH;               // W wave-instructions per wave per K-tile
   constexpr int PW = 18, PPIX = 18 * 18;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -112,8 +121,17 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
   auto issue_w = [&](int buf) __attribute__((always_inline)) {
     const int cc = w_kt / 9, tap = w_kt - cc * 9;
     const uint32_t koff = (uint32_t)(tap * p.Cin + cc * 64) * (uint32_t)sizeof(T);
+    if constexpr (N160) {
+      const uint32_t dst = lds0 + (buf ? 0x20000u : 0x18000u) + (uint32_t)wave * 1024u;
 #pragma unroll
-    for (int h = 0; h < WH; ++h) {
+      for (int j = 0; j < 3; ++j) {      // rows j * 64 + wave * 8 + lrow of the 160 (j = 2: waves 0-3; the others write zeros)
+        const uint32_t off = w_v0 + (uint32_t)(j * 64) * (uint32_t)p.K * (uint32_t)sizeof(T) + koff;
+        const bool ok = w_live && (j < 2 || wave < 4);
+        dma16(rw, ok ? off : kOOB, dst + j * 8192);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < (N160 ? 0 : WH); ++h) {
       const uint32_t dst = lds0 + (uint32_t)(WB + h * 32768 + buf * HT) + (uint32_t)wave * 1024u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -140,7 +158,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
   {
     const int l15 = lane & 15, l4 = lane >> 4;
     const uint32_t fb = (uint32_t)(l15 * 128 + ((l4 ^ (l15 >> 1)) << 4));
-    wb0 = (uint32_t)(WB + (wc >> 1) * 32768 + (wc & 1) * 64 * 128) + fb;
+    if constexpr (N160) wb0 = (uint32_t)(WB + wc * 80 * 128) + fb;      // rows wc * 80 .. + 79 (80 / 2 = 0 mod 8: same swizzle term)
+    else wb0 = (uint32_t)(WB + (wc >> 1) * 32768 + (wc & 1) * 64 * 128) + fb;
     wb1 = wb0 ^ 64u;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
@@ -151,13 +170,13 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
       }
   }
 
-  f32x4 acc6[MB6][4];
-  typename Tr<T>::v8 fa[MH][2], fw0[2][2], fw1[2][2];
+  f32x4 acc6[MB6][NBW];
+  typename Tr<T>::v8 fa[MH][2], fw0[2][2], fw1[2][2], fw4[2];     // fw4: the fifth column block of the 80-wide wave tile
   auto zero6 = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MB6; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc6[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NBW; ++j) acc6[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto bar = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
@@ -186,6 +205,16 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
       fw[j][1] = as_v8<T>(*(const i32x4*)(smem + wb1 + (32 * u + 16 * j) * 128));
     }
   };
+  auto read_w4 = [&]() __attribute__((always_inline)) {
+    fw4[0] = as_v8<T>(*(const i32x4*)(smem + wb0 + 64 * 128));
+    fw4[1] = as_v8<T>(*(const i32x4*)(smem + wb1 + 64 * 128));
+  };
+  auto mfmas4 = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < MH; ++i) acc6[MH * s + i][NBW - 1] = Tr<T>::mfma16(fw4[kh], fa[i][kh], acc6[MH * s + i][NBW - 1]);
+  };
   auto mfmas = [&](int s, int u, const typename Tr<T>::v8 (&fw)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -204,6 +233,52 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
+    if constexpr (N160) {
+      // 64 x 80 wave tile: 32 rows per round through 160-byte staging rows (5 KiB per wave, `stg` is this wave's), stored as ten
+      // 16-byte chunks per row = one contiguous 160-byte run of the output row; no fused statistics (10 channels per group)
+#pragma unroll
+      for (int i = 0; i < MB6 / 2; ++i) {
+        f32x4 add[2][NBW];
+        i32x2 res[2][NBW];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = row_to_m(c, wm * WTM + i * 32 + h * 16 + l15);
+#pragma unroll
+          for (int j = 0; j < NBW; ++j) {
+            const int n = c.n0 + wc * 80 + j * 16 + 4 * l4;
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bb = *(const f32x4*)(p.bias + n);
+            if (p.rowbias) {
+              const f32x4 r = *(const f32x4*)(p.rowbias + (size_t)c.img * p.ldrb + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bb[e] += r[e];
+            }
+            add[h][j] = bb;
+            res[h][j] = i32x2{0, 0};
+            if (p.residual) res[h][j] = *(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T));
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < NBW; ++j) {
+            float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) unpack4<T>(res[h][j], r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc6[2 * i + h][j][e] + add[h][j][e] + r[e]) * p.out_scale;
+            *(i32x2*)(stg + (h * 16 + l15) * 160 + j * 32 + l4 * 8) = pack4<T>(v);
+          }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const int idx = lane + 64 * t;               // 320 chunks of the round
+          const int r = (idx * 6554) >> 16, ch = idx - r * 10;
+          const int m2 = row_to_m(c, wm * WTM + i * 32 + r);
+          const i32x4 val = *(const i32x4*)(stg + r * 160 + ch * 16);
+          *(i32x4*)(Cb + ((size_t)m2 * p.ldc + c.n0 + wc * 80 + ch * 8) * sizeof(T)) = val;
+        }
+      }
+      return;
+    }
     float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int i = 0; i < MB6 / 2; ++i) {
@@ -290,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
   nx_advance();
   issue_w(0);
   issue_w(1);
-  wait_vm<2 * WH>();
+  wait_vm<WDMA>();
   bar();
   if (wr == 1) bar();                       // the stagger: wave group 1 runs one barrier behind group 0
   zero6();
@@ -306,21 +381,24 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
         read_a(0, tap);
         read_w(fw0, 0);
         read_w(fw1, 1);
+        if constexpr (N160) read_w4();
         if (tap >= 1 && tap <= 6) issue_piece(tap - 1, pb ^ 1);
         lgkm0();
         bar();
         __builtin_amdgcn_s_setprio(1);
         mfmas(0, 0, fw0);
         mfmas(0, 1, fw1);
+        if constexpr (N160) mfmas4(0);
         __builtin_amdgcn_s_setprio(0);
         bar();
         // PB
         read_a(1, tap);
         issue_w(wbuf);                      // W(g+2) -> the buffer this K-tile's W came from
-        wait_vm<2 * WH>();
+        wait_vm<WDMA>();
         lgkm0();
         bar();
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (N160) mfmas4(1);
         mfmas(1, 1, fw1);
         mfmas(1, 0, fw0);
         __builtin_amdgcn_s_setprio(0);
@@ -338,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch8_kernel(const GemmP p) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) ab[kx][rr] += d;
           if (last) {
-            epilogue6(ct, smem + pb * PATCH + wave * 4096, tile0 + ti * nxb);
+            epilogue6(ct, smem + pb * PATCH + wave * (N160 ? 5120 : 4096), tile0 + ti * nxb);
             zero6();
             if (ti + 1 < my_tiles) ct = tile_coords(tile0 + (ti + 1) * nxb);
             if (wr == 1) bar();
@@ -362,7 +440,7 @@ static int launch_patch8(const GemmP& p, hipStream_t st, int gn_chunks) {
   q.tpi = q.tpr * (p.Ho / 16);
   q.gn_chunks = p.gn_partial ? gn_chunks : 0;
   if (q.gn_chunks == 0) q.gn_partial = nullptr;
-  constexpr size_t lds = 2 * 49152 + (size_t)(BN / 128) * 32768;
+  constexpr size_t lds = BN == 160 ? (size_t)0x26000 : 2 * 49152 + (size_t)(BN / 128) * 32768;
   int nwg = q.ntm * q.ntn;
   if (nwg > 256) nwg = 256;
   nwg = (nwg + 7) & ~7;
@@ -387,6 +465,10 @@ bool conv_patch8_eligible(const GemmP& p, int& bn) {
   if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || p.res_f32) return false;
   if (p.rows_per_img != p.Ho * p.Wo) return false;
   const long long mt = p.M / 256;
+  if ((p.N % 160) == 0 && (p.N % 128) != 0 && mt * (p.N / 160) >= cfg().big_min_tiles) {
+    bn = 160;       // N = 320 (the UNet's 64^2 level on the lock-step batch: 128 x 2 = 256 tiles, one per CU)
+    return true;
+  }
   if ((p.N % 256) == 0) {
     // too few 256 x 256 tiles for the chip (the VAE's 64^2 level on 4 images: 128): the 256 x 128 tile doubles the count
     bn = (mt * (p.N / 256) >= cfg().big_min_tiles) ? 256 : 128;
@@ -397,7 +479,7 @@ bool conv_patch8_eligible(const GemmP& p, int& bn) {
 
 int conv_patch8_gn_chunks(const GemmP& p) {
   int bn = 0;
-  if (p.gn_groups <= 0 || !conv_patch8_eligible(p, bn) || p.N % p.gn_groups) return 0;
+  if (p.gn_groups <= 0 || !conv_patch8_eligible(p, bn) || bn == 160 || p.N % p.gn_groups) return 0;
   const int cpg = p.N / p.gn_groups;
   if (cpg < 4 || cpg > 64 || (cpg & (cpg - 1))) return 0;
   return (p.Wo / 16) * (p.Ho / 16) * (8 / (bn / 64));
@@ -408,6 +490,7 @@ int launch_conv_patch8(const GemmP& p, hipStream_t st) {
   if (!conv_patch8_eligible(p, bn)) return DFW_ESHAPE;
   const int chunks = conv_patch8_gn_chunks(p);
   const bool bf = p.dtype_bf16 != 0;
+  if (bn == 160) return bf ? launch_patch8<__bf16, 160>(p, st, chunks) : launch_patch8<_Float16, 160>(p, st, chunks);
   if (bn == 256) return bf ? launch_patch8<__bf16, 256>(p, st, chunks) : launch_patch8<_Float16, 256>(p, st, chunks);
   return bf ? launch_patch8<__bf16, 128>(p, st, chunks) : launch_patch8<_Float16, 128>(p, st, chunks);
 }

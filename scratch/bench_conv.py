@@ -9,7 +9,7 @@ shapes = {"vae512": (12, 512, 512, 128, 128), "vae256": (12, 256, 256, 256, 256)
           "unet8": (4, 8, 8, 1280, 1280), "dec512": (4, 512, 512, 128, 128), "b1_512": (1, 512, 512, 128, 128), "b2_512": (2, 512, 512, 128, 128),
           "b24_512": (24, 512, 512, 128, 128), "k2304n128": (12, 256, 256, 256, 128), "k1152n256": (12, 256, 256, 128, 256),
           "dec64": (4, 64, 64, 512, 512), "enc64": (12, 64, 64, 512, 512), "dec128": (4, 128, 128, 512, 512), "unet32": (8, 32, 32, 640, 640),
-          "unet64b8": (8, 64, 64, 320, 320), "dec256": (4, 256, 256, 256, 256)}
+          "unet64b8": (8, 64, 64, 320, 320), "unet64k2": (8, 64, 64, 640, 320), "unet64k3": (8, 64, 64, 960, 320), "dec256": (4, 256, 256, 256, 256)}
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(shapes)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for n in names:

@@ -366,14 +366,16 @@ def test_gemm8_conv_gather(ops, dtype, B, H, W, Cin, Cout, stride, pad, ups):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(12, 128, 128, 256, 256), (3, 512, 512, 128, 128), (2, 256, 256, 64, 128), (3, 128, 128, 320, 256),
                                             (1, 320, 336, 64, 320), (4, 64, 64, 320, 320), (2, 96, 160, 192, 512), (1, 256, 256, 128, 384),
-                                            (4, 64, 64, 512, 512)])
+                                            (4, 64, 64, 512, 512), (8, 64, 64, 320, 320), (8, 64, 64, 640, 320), (12, 64, 64, 192, 320),
+                                            (2, 128, 128, 64, 320)])
 def test_conv_patch8(ops, dtype, B, H, W, Cin, Cout):
     """conv_patch8_kernel (round 4: the LDS-resident 18 x 18 x 64-channel patch on the eight-phase schedule; dfw_config.conv_patch = 4
     plans its 256 x 256 tile for N % 256 == 0 and its 256 x 128 tile for the other N % 64 == 0 layers): against F.conv2d on the
     same 16-bit inputs (first and last image: all four borders), against conv_patch_kernel / gemm_kernel (conv_patch = 2: same
     products, another summation order), run-to-run bit-equal, fused GroupNorm sums.  One chunk per tile (Cin = 64: the staging
     area and the next tile's patch alternate every tile), odd chunk counts (Cin = 320, 192), several tiles per workgroup,
-    ragged N (320 = 2.5 column tiles), N % 256 == 0 with too few 256 x 256 tiles (4 x 64^2 x 512: the 256 x 128 tile)."""
+    ragged N (320 = 2.5 column tiles), N % 256 == 0 with too few 256 x 256 tiles (4 x 64^2 x 512: the 256 x 128 tile), N = 320 with enough rows for
+    its 256 x 160 tile (64 x 80 wave tiles, 160-byte staging rows; one and several tiles per workgroup, one and ten chunks)."""
     from diffews_amd import _lib
     from diffews_amd.packing import pack_conv3x3
     x = rnd((B, H, W, Cin), dtype, 1).cuda()
