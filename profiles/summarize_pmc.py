@@ -26,6 +26,9 @@ def readable(mangled):
     m = re.search(r"gemm8_kernelIDF16(b|_)Lb(\d)ELi(\d+)E", mangled)
     if m:      # the name dfw_gemm_kernel_name() gives bench.py
         return f"gemm8_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},256,{m.group(3)},64,{'conv' if m.group(2) == '1' else 'lin'}>"
+    m = re.search(r"gemm8_kernel<bool _Accum, bool, E, (\d+)>", mangled)
+    if m:      # rocprofv3's demangler garbles the CONV = true instantiation (the only one whose name it prints demangled)
+        return f"gemm8_kernel<bf16,256,{m.group(1)},64,conv>"
     m = re.search(r"conv_patch8_kernelIDF16(b|_)Li(\d+)E", mangled)
     if m:      # the name dfw_gemm_kernel_name() gives bench.py
         return f"conv_patch8_kernel<{'bf16' if m.group(1) == 'b' else 'f16'},256,{m.group(2)}>"
