@@ -495,6 +495,10 @@ extern "C" int dfw_gemm_kernel_name(const dfw_gemm_args* a, char* buf, size_t n)
   if (rc) return rc;
   if (!buf || n == 0) return DFW_EINVAL;
   int big_bm = 0, big_bn = 0, big_bk = 0;
+  if (gemm8_n160_eligible(p)) {
+    snprintf(buf, n, "gemm8_kernel<%s,256,160,64,lin>", a->dtype == DFW_BF16 ? "bf16" : "f16");
+    return 0;
+  }
   {
     int pbm = 0, pbn = 0;
     if (conv_patch8_eligible(p, pbn)) {
@@ -547,6 +551,7 @@ extern "C" int dfw_gemm(const dfw_gemm_args* a, dfw_stream_t stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   int big_bm = 0, big_bn = 0, big_bk = 0;
+  if (gemm8_n160_eligible(p)) return launch_gemm8(p, st, 160);
   {
     int pbm = 0, pbn = 0;
     if (conv_patch8_eligible(p, pbn)) return launch_conv_patch8(p, st);

@@ -33,10 +33,18 @@ namespace dfw {
 template <typename T, bool CONV, int BN>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
   constexpr int BM = 256, HT = 16384;
+  // BN = 160 (Linear only; the N = 320 layers of the UNet's 64^2 level: 128 x 2 = 256 tiles on the lock-step batch): wave grid 4 x 2,
+  // wave tile 64 x 80 (five 16-column blocks), ONE 160-row W stage per K-tile (three wave-instructions per wave, the third of waves
+  // 4-7 zero-fills 32 pad rows) in two 24 KiB buffers behind the A half-tile slots, 160-byte staging rows (conv_patch8.hip's tile)
+  constexpr bool N160 = BN == 160;
+  static_assert(!(N160 && CONV), "the 256 x 160 tile is instantiated for Linear shapes only");
   constexpr int WH = BN / 128;                          // W half-tiles per K-tile
-  constexpr int WGN = BN / 64, WGM = 8 / WGN;           // wave grid
+  constexpr int WGN = N160 ? 2 : BN / 64, WGM = 8 / WGN;   // wave grid
+  constexpr int NBW = N160 ? 5 : 4;                     // 16-column blocks of a wave tile
   constexpr int WTM = BM / WGM, MB6 = WTM / 16, MH = MB6 / 2;   // wave tile rows, its 16-row blocks, blocks per quadrant
-  constexpr int STG = (2 + WH) * 32768;                 // epilogue staging behind the half-tile slots
+  constexpr int WDMA = N160 ? 3 : 2 * WH;               // W wave-instructions per wave per K-tile
+  constexpr int WB160 = 65536, WS160 = 24576;           // BN = 160: W buffers at WB160 + buf * WS160
+  constexpr int STG = N160 ? WB160 + 2 * WS160 : (2 + WH) * 32768;   // epilogue staging behind the stage slots
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,8 +168,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
       const int cc = w_kt / 9, tap = w_kt - cc * 9;
       koff = (uint32_t)(tap * p.Cin + cc * 64) * (uint32_t)sizeof(T);
     }
+    if constexpr (N160) {
+      const uint32_t dst = lds0 + (uint32_t)(WB160 + buf * WS160) + (uint32_t)wave * 1024u;
 #pragma unroll
-    for (int h = 0; h < WH; ++h) {
+      for (int j = 0; j < 3; ++j) {      // rows j * 64 + wave * 8 + lrow of the 160 (j = 2: waves 0-3; the others write zeros)
+        const uint32_t off = w_v0 + (uint32_t)(j * 64) * (uint32_t)p.K * (uint32_t)sizeof(T) + koff;
+        const bool ok = w_live && (j < 2 || wave < 4);
+        dma16(rw, ok ? off : kOOB, dst + j * 8192);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < (N160 ? 0 : WH); ++h) {
       const uint32_t dst = lds0 + (uint32_t)((2 + h) * 32768 + buf * HT) + (uint32_t)wave * 1024u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -186,17 +203,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
     const uint32_t fb = (uint32_t)(l15 * 128 + ((l4 ^ (l15 >> 1)) << 4));
     ab0 = (uint32_t)(wr * 32768 + (wm % (WGM / 2)) * WTM * 128) + fb;
     ab1 = ab0 ^ 64u;
-    wb0 = (uint32_t)((2 + (wc >> 1)) * 32768 + (wc & 1) * 64 * 128) + fb;
+    if constexpr (N160) wb0 = (uint32_t)(WB160 + wc * 80 * 128) + fb;   // rows wc * 80 .. + 79 (80 / 2 = 0 mod 8: the same swizzle term)
+    else wb0 = (uint32_t)((2 + (wc >> 1)) * 32768 + (wc & 1) * 64 * 128) + fb;
     wb1 = wb0 ^ 64u;
   }
+  const uint32_t wbase160 = wb0;
 
-  f32x4 acc6[MB6][4];
-  typename Tr<T>::v8 fa[MH][2], fw0[2][2], fw1[2][2];
+  f32x4 acc6[MB6][NBW];
+  typename Tr<T>::v8 fa[MH][2], fw0[2][2], fw1[2][2], fw4[2];     // fw4: the fifth column block of the 80-wide wave tile
   auto zero6 = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MB6; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc6[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NBW; ++j) acc6[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto bar = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
@@ -222,6 +241,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
       fw[j][1] = as_v8<T>(*(const i32x4*)(smem + wb1 + (32 * u + 16 * j) * 128));
     }
   };
+  auto read_w4 = [&]() __attribute__((always_inline)) {
+    fw4[0] = as_v8<T>(*(const i32x4*)(smem + wb0 + 64 * 128));
+    fw4[1] = as_v8<T>(*(const i32x4*)(smem + wb1 + 64 * 128));
+  };
+  auto mfmas4 = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < MH; ++i) acc6[MH * s + i][NBW - 1] = Tr<T>::mfma16(fw4[kh], fa[i][kh], acc6[MH * s + i][NBW - 1]);
+  };
   auto mfmas = [&](int s, int u, const typename Tr<T>::v8 (&fw)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -240,6 +269,54 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int l15 = lane_e & 15, l4 = lane_e >> 4, lane = lane_e;
+    if constexpr (N160) {
+      // 64 x 80 wave tile: 32 rows per round through 160-byte staging rows (5 KiB per wave), stored as ten 16-byte chunks per row
+#pragma unroll
+      for (int i = 0; i < MB6 / 2; ++i) {
+        f32x4 add[2][NBW];
+        i32x2 res[2][NBW];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = c.m0 + wm * WTM + i * 32 + h * 16 + l15;
+          const int img_ = (p.rowbias && m < p.M) ? m / p.rows_per_img : 0;
+#pragma unroll
+          for (int j = 0; j < NBW; ++j) {
+            const int n = c.n0 + wc * 80 + j * 16 + 4 * l4;
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bb = *(const f32x4*)(p.bias + n);
+            if (p.rowbias && m < p.M) {
+              const f32x4 r = *(const f32x4*)(p.rowbias + (size_t)img_ * p.ldrb + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bb[e] += r[e];
+            }
+            add[h][j] = bb;
+            res[h][j] = i32x2{0, 0};
+            if (p.residual && m < p.M) res[h][j] = *(const i32x2*)(p.residual + ((size_t)m * p.ldr + n) * sizeof(T));
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < NBW; ++j) {
+            float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) unpack4<T>(res[h][j], r);
+            const float osc = (c.n0 + wc * 80 + j * 16) < p.cs_n ? p.cs : p.out_scale;     // cs_n is a multiple of 64: whole 16-column blocks
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc6[2 * i + h][j][e] + add[h][j][e] + r[e]) * osc;
+            *(i32x2*)(stg + (h * 16 + l15) * 160 + j * 32 + l4 * 8) = pack4<T>(v);
+          }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const int idx = lane + 64 * t;               // 320 chunks of the round
+          const int r = (idx * 6554) >> 16, ch = idx - r * 10;
+          const int m2 = c.m0 + wm * WTM + i * 32 + r;
+          const i32x4 val = *(const i32x4*)(stg + r * 160 + ch * 16);
+          if (m2 < p.M)
+            *(i32x4*)(Cb + ((size_t)m2 * p.ldc + c.n0 + wc * 80 + ch * 8) * sizeof(T)) = val;
+        }
+      }
+      return;
+    }
     float gs0 = 0.f, gs1 = 0.f, gq0 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int i = 0; i < MB6 / 2; ++i) {
@@ -347,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
   issue_w(0);
   issue_a(0);
   issue_w(1);
-  wait_vm<2 * WH>();
+  wait_vm<WDMA>();
   bar();
   if (wr == 1) bar();                       // the stagger: wave group 1 runs one barrier behind group 0
   zero6();
@@ -359,21 +436,24 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
     read_a(0);
     read_w(fw0, 0);
     read_w(fw1, 1);
+    if constexpr (N160) read_w4();
     issue_a(buf ^ 1);
     lgkm0();
     bar();
     __builtin_amdgcn_s_setprio(1);
     mfmas(0, 0, fw0);
     mfmas(0, 1, fw1);
+    if constexpr (N160) mfmas4(0);
     __builtin_amdgcn_s_setprio(0);
     bar();
     // PB
     read_a(1);
     issue_w(buf);
-    wait_vm<2 * WH>();
+    wait_vm<WDMA>();
     lgkm0();
     bar();
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (N160) mfmas4(1);
     mfmas(1, 1, fw1);
     mfmas(1, 0, fw0);
     __builtin_amdgcn_s_setprio(0);
@@ -382,9 +462,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmP p) {
     // the two epilogues then run side by side instead of one after the other
     if (!(last && wr == 1)) bar();
     buf ^= 1;
-    ab0 ^= (uint32_t)HT; ab1 ^= (uint32_t)HT; wb0 ^= (uint32_t)HT; wb1 ^= (uint32_t)HT;
+    ab0 ^= (uint32_t)HT; ab1 ^= (uint32_t)HT;
+    if constexpr (N160) { wb0 = wbase160 + (uint32_t)(buf * WS160); wb1 = wb0 ^ 64u; }
+    else { wb0 ^= (uint32_t)HT; wb1 ^= (uint32_t)HT; }
     if (last) {
-      epilogue6(ct, smem + STG + wave * 4096, tile0 + ti * nxb);
+      epilogue6(ct, smem + STG + wave * (N160 ? 5120 : 4096), tile0 + ti * nxb);
       zero6();
       kt = 0;
       ++ti;
@@ -411,7 +493,7 @@ static int launch8(const GemmP& p, hipStream_t st) {
     q.tpr = p.Wo / 16;
     q.tpi = q.tpr * (p.Ho / 16);
   }
-  constexpr size_t lds = (size_t)(2 + BN / 128) * 32768 + 32768;
+  constexpr size_t lds = BN == 160 ? (size_t)(65536 + 2 * 24576 + 8 * 5120) : (size_t)(2 + BN / 128) * 32768 + 32768;
   const int zdim = p.batch > 1 ? p.batch : 1;
   int nwg = q.ntm * q.ntn;
   if (nwg > 256) nwg = 256;
@@ -421,10 +503,12 @@ static int launch8(const GemmP& p, hipStream_t st) {
     auto kfn = gemm8_kernel<T, false, BN>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
-  } else {
+  } else if constexpr (BN != 160) {
     auto kfn = gemm8_kernel<T, true, BN>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, q);
+  } else {
+    return DFW_ESHAPE;
   }
   DFW_CHECK_LAUNCH();
   return 0;
@@ -439,7 +523,17 @@ bool gemm8_eligible(const GemmP& p, int bn) {
   return bn == 128 && (p.N % 64) == 0 && cfg().k8 >= 2;
 }
 
+// The 256 x 160 tile: Linear shapes with N a multiple of 160 but not of 128 (the UNet's 320-channel 64^2 level: to_out, proj_in /
+// proj_out, FF2; N = 960: the fused QKV projection with its column scale) and enough rows that its tiles fill the chip; bias / row bias /
+// residual / column-scale epilogue (no GEGLU, no activation).
+bool gemm8_n160_eligible(const GemmP& p) {
+  if (!cfg().k8 || !cfg().big_kernels || p.taps != 1 || p.out_mode != DFW_OUT_T || p.res_f32 || p.geglu || p.act != DFW_ACT_NONE) return false;
+  if (p.batch > 1 || p.splitk > 1 || (p.N % 160) != 0 || (p.N % 128) == 0 || (p.K % 64) != 0 || p.K / 64 < 2) return false;
+  return (long long)((p.M + 255) / 256) * (p.N / 160) >= cfg().big_min_tiles;
+}
+
 int launch_gemm8(const GemmP& p, hipStream_t st, int bn) {
+  if (bn == 160) return p.dtype_bf16 ? launch8<__bf16, 160>(p, st) : launch8<_Float16, 160>(p, st);
   if (bn == 256) return p.dtype_bf16 ? launch8<__bf16, 256>(p, st) : launch8<_Float16, 256>(p, st);
   return p.dtype_bf16 ? launch8<__bf16, 128>(p, st) : launch8<_Float16, 128>(p, st);
 }

@@ -244,6 +244,7 @@ bool gemm_big_eligible(const GemmP& p, int& bm, int& bn, int& bk);
 int gemm_big_gn_chunks(const GemmP& p);   // > 0: the planned big kernel can emit GroupNorm partials
 int launch_gemm8(const GemmP& p, hipStream_t st, int bn);   // gemm8.hip
 bool gemm8_eligible(const GemmP& p, int bn);
+bool gemm8_n160_eligible(const GemmP& p);   // the 256 x 160 Linear tile (N = 320 at the UNet's 64^2 level)
 int launch_conv_patch(const GemmP& p, hipStream_t st);  // conv_patch.hip
 bool conv_patch_eligible(const GemmP& p, int& bm, int& bn);
 int conv_patch_gn_chunks(const GemmP& p);

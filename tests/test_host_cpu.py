@@ -378,9 +378,10 @@ def test_kernel_plans_of_the_baseline_shapes():
     assert name(4 * 64 * 64, 320, 9 * 320, 9, 64, 64).startswith("gemm_kernel<bf16,")
     # UNet, lock-step batch of 8 latents: narrow tiles for the short-K linears, the ragged 960-column QKV on gemm_big
     assert name(8192, 640, 640) in ("gemm_kernel<bf16,64,64,lin>", "gemm_kernel<bf16,128,64,lin>")   # never 128 x 128 (+47 %)
-    assert name(32768, 960, 320) == "gemm8_kernel<bf16,256,128,64,lin>"          # round 4: the 64-deep K-tile kernel, 256 x 128 tile
+    assert name(32768, 960, 320) == "gemm8_kernel<bf16,256,160,64,lin>"          # round 4: the 64-deep K-tile kernel, 256 x 160 tile (6 x 160)
     assert name(32768, 2560, 320) == "gemm8_kernel<bf16,256,256,64,lin>"
-    assert name(32768, 320, 320).startswith("gemm_kernel<bf16,")
+    assert name(32768, 320, 320) == "gemm8_kernel<bf16,256,160,64,lin>"          # 128 x 2 = 256 tiles, one per CU
+    assert name(8192, 640, 640).startswith("gemm_kernel<bf16,")                  # too few rows for 256-row tiles
 
     def fsa_ws(batch, n_plain, nshot, heads, n):
         a = _lib.FsaArgs()

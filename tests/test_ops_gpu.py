@@ -321,6 +321,37 @@ def test_gemm8_linear(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(32768, 320, 320), (33000, 320, 1280), (49152, 320, 128), (70000, 320, 640), (40000, 960, 320)])
+def test_gemm8_linear_n160(ops, dtype, M, N, K):
+    """gemm8_kernel's 256 x 160 tile (round 4: the N = 320 linears of the UNet's 64^2 level; 64 x 80 wave tiles, one 160-row W stage
+    per K-tile, 160-byte staging rows): against the fp32 reference and against gemm_kernel (dfw_config.k8 = 0: same products,
+    another summation order); ragged M, two K-tiles per tile, one and several tiles per workgroup, bias / residual / row bias /
+    column scale (N = 960: the fused QKV projection)."""
+    from diffews_amd import _lib
+    x, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+    bias, res = torch.randn(N).cuda(), rnd((M, N), dtype, 3).cuda()
+    rpi = 4096
+    rb = torch.randn((M + rpi - 1) // rpi, N).cuda()
+    kw = dict(bias=bias, residual=res, rowbias=rb, rows_per_img=rpi, out_scale=0.5, colscale=(64, 0.25))
+    try:
+        names = _kernel_name(ops, lambda: ops.linear(x, w, **kw))
+        assert names == ["gemm8_kernel<%s,256,160,64,lin>" % ("bf16" if dtype == torch.bfloat16 else "f16")], names
+        y8 = ops.linear(x, w, **kw)
+        y8b = ops.linear(x, w, **kw)
+        _lib.configure(k8=0)
+        y0 = ops.linear(x, w, **kw)
+    finally:
+        _lib.configure()
+    ref = x.float() @ w.float().t() + bias + res.float() + rb.repeat_interleave(rpi, 0)[:M]
+    ref = torch.cat([ref[:, :64] * 0.25, ref[:, 64:] * 0.5], 1)
+    assert rel(y8, ref) < TOL[dtype]
+    assert rel(y8, y0) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert torch.equal(y8, y8b)
+    # a plain call (no epilogue operands)
+    assert rel(ops.linear(x, w), x.float() @ w.float().t()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pad,ups", [(3, 128, 128, 64, 256, 1, 1, True), (4, 256, 256, 128, 256, 2, 0, False),
                                                           (12, 128, 128, 320, 256, 2, 1, False), (2, 96, 160, 192, 512, 1, 1, True),
                                                           (4, 256, 256, 128, 128, 2, 0, False), (3, 64, 64, 640, 128, 1, 1, True), (3, 64, 64, 320, 384, 1, 1, True)])
