@@ -9,8 +9,9 @@
 // the 9 x 32 KB gemm8_kernel<conv> gathers.  The next chunk's patch arrives in six pieces per wave, one per tap in the
 // PA phases of taps 1..6 (one LDS-DMA instruction beside the tap's W half-tiles' four).
 //
-// LDS (160 KiB): patch 0 | patch 1 (48 KiB each: 6 pieces x 8 waves x 1 KiB) | W half-tile slots (BN / 128 x 2 x 16 KiB).
-// The epilogue's 32 KiB staging area is the patch buffer the tile has just RETIRED (its last reader's ds_reads returned
+// LDS (160 KiB): patch 0 | patch 1 (48 KiB each: 6 pieces x 8 waves x 1 KiB) | W half-tile slots (BN / 128 x 2 x 16 KiB; the
+// 256 x 160 tile: two 24 KiB stages of 160 + 32 pad rows at 0x18000 / 0x20000, 152 KiB in all).
+// The epilogue's 32 KiB (256 x 160 tile: 40 KiB) staging area is the patch buffer the tile has just RETIRED (its last reader's ds_reads returned
 // before the barrier in front of the tile's last 32 MFMAs; the next writer of that buffer is the patch of the NEXT tile's
 // second chunk, issued from that tile's tap 1 on, four barriers behind both groups' epilogues).
 //
