@@ -465,6 +465,7 @@ bool conv_patch8_eligible(const GemmP& p, int& bn) {
   if (p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % 16) != 0 || (p.Ho % 16) != 0 || (p.Cin % 64) != 0 || (p.M % 256) != 0) return false;
   if (p.out_mode != DFW_OUT_T || p.act != DFW_ACT_NONE || p.geglu || p.cs_n > 0 || p.res_f32) return false;
   if (p.rows_per_img != p.Ho * p.Wo) return false;
+  if ((p.ldc % 8) != 0 || ((uintptr_t)p.C & 15)) return false;      // the epilogues store 16-byte chunks of output rows
   const long long mt = p.M / 256;
   if ((p.N % 160) == 0 && (p.N % 128) != 0 && mt * (p.N / 160) >= cfg().big_min_tiles) {
     bn = 160;       // N = 320 (the UNet's 64^2 level on the lock-step batch: 128 x 2 = 256 tiles, one per CU)

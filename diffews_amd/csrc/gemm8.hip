@@ -529,6 +529,7 @@ bool gemm8_eligible(const GemmP& p, int bn) {
 bool gemm8_n160_eligible(const GemmP& p) {
   if (!cfg().k8 || !cfg().big_kernels || p.taps != 1 || p.out_mode != DFW_OUT_T || p.res_f32 || p.geglu || p.act != DFW_ACT_NONE) return false;
   if (p.batch > 1 || p.splitk > 1 || (p.N % 160) != 0 || (p.N % 128) == 0 || (p.K % 64) != 0 || p.K / 64 < 2) return false;
+  if ((p.ldc % 8) != 0 || ((uintptr_t)p.C & 15)) return false;      // the epilogue stores 16-byte chunks of output rows
   return (long long)((p.M + 255) / 256) * (p.N / 160) >= cfg().big_min_tiles;
 }
 
